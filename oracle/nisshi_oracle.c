@@ -1,0 +1,696 @@
+/*
+ * CPU restatement of the nisshi-sans-io RecordBatch v2 codec.
+ * TEST INFRASTRUCTURE ONLY: see nisshi_oracle.h.  Citations are paths inside
+ * the reference tree.
+ */
+#include "nisshi_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ CRC-32C */
+
+static uint32_t crc_table[8][256];
+static int crc_table_ready;
+
+static void crc_init(void) {
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+        crc_table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; i++)
+        for (int t = 1; t < 8; t++)
+            crc_table[t][i] = (crc_table[t - 1][i] >> 8) ^ crc_table[0][crc_table[t - 1][i] & 0xff];
+    crc_table_ready = 1;
+}
+
+uint32_t no_crc32c(const uint8_t *data, size_t len) {
+    if (!crc_table_ready) crc_init();
+    uint32_t c = 0xFFFFFFFFu;
+    while (len >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, data, 4);
+        memcpy(&hi, data + 4, 4);
+        lo ^= c;
+        c = crc_table[7][lo & 0xff] ^ crc_table[6][(lo >> 8) & 0xff] ^
+            crc_table[5][(lo >> 16) & 0xff] ^ crc_table[4][lo >> 24] ^ crc_table[3][hi & 0xff] ^
+            crc_table[2][(hi >> 8) & 0xff] ^ crc_table[1][(hi >> 16) & 0xff] ^
+            crc_table[0][hi >> 24];
+        data += 8;
+        len -= 8;
+    }
+    while (len--) c = (c >> 8) ^ crc_table[0][(c ^ *data++) & 0xff];
+    return c ^ 0xFFFFFFFFu;
+}
+
+/* ------------------------------------------------------------------ varints */
+
+/* VarInt::decode, primitive/varint.rs:49-78.  shift advances 0,7,..,28,35;
+ * u32::checked_shl fails only once shift >= 32, so a 5th byte's upper bits are
+ * silently dropped and a 6th byte is Error::Overflow.  The byte is fetched
+ * (try_get_u8) before the shift is checked, so under-run wins over overflow.
+ * checked_add cannot overflow: every addend occupies bits above the sum so far. */
+int no_varint_decode(const uint8_t *buf, size_t len, size_t *pos, int32_t *out) {
+    uint32_t shift = 0, acc = 0;
+    for (;;) {
+        if (*pos >= len) return NO_TRY_GET;
+        uint8_t byte = buf[(*pos)++];
+        if (shift >= 32) return NO_OVERFLOW;
+        if (byte & 0x80) {
+            acc += (uint32_t)(byte & 0x7f) << shift;
+            shift += 7;
+        } else {
+            acc += (uint32_t)byte << shift;
+            break;
+        }
+    }
+    /* de_zigzag :107-109 */
+    *out = (int32_t)(acc >> 1) ^ -(int32_t)(acc & 1);
+    return NO_OK;
+}
+
+/* LongVarInt::decode, varint.rs:266-295: the same with u64; the 11th byte overflows. */
+int no_varlong_decode(const uint8_t *buf, size_t len, size_t *pos, int64_t *out) {
+    uint32_t shift = 0;
+    uint64_t acc = 0;
+    for (;;) {
+        if (*pos >= len) return NO_TRY_GET;
+        uint8_t byte = buf[(*pos)++];
+        if (shift >= 64) return NO_OVERFLOW;
+        if (byte & 0x80) {
+            acc += (uint64_t)(byte & 0x7f) << shift;
+            shift += 7;
+        } else {
+            acc += (uint64_t)byte << shift;
+            break;
+        }
+    }
+    *out = (int64_t)(acc >> 1) ^ -(int64_t)(acc & 1); /* :303-306 */
+    return NO_OK;
+}
+
+/* UnsignedVarInt::deserialize, varint.rs:476-534 (same loop, no zigzag) */
+int no_uvarint_decode(const uint8_t *buf, size_t len, size_t *pos, uint32_t *out) {
+    uint32_t shift = 0, acc = 0;
+    for (;;) {
+        if (*pos >= len) return NO_TRY_GET;
+        uint8_t byte = buf[(*pos)++];
+        if (shift >= 32) return NO_OVERFLOW;
+        if (byte & 0x80) {
+            acc += (uint32_t)(byte & 0x7f) << shift;
+            shift += 7;
+        } else {
+            acc += (uint32_t)byte << shift;
+            break;
+        }
+    }
+    *out = acc;
+    return NO_OK;
+}
+
+static uint32_t zigzag32(int32_t v) { /* varint.rs:102-104 */
+    return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
+}
+static uint64_t zigzag64(int64_t v) { /* varint.rs:299-301 */
+    return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63);
+}
+
+size_t no_uvarint_size(uint32_t v) { /* varint.rs:546-556 */
+    size_t n = 1;
+    while (v >= 0x80) {
+        v >>= 7;
+        n++;
+    }
+    return n;
+}
+size_t no_varint_size(int32_t v) { return no_uvarint_size(zigzag32(v)); } /* :186-196 */
+size_t no_varlong_size(int64_t v) {                                       /* :379-389 */
+    uint64_t z = zigzag64(v);
+    size_t n = 1;
+    while (z >= 0x80) {
+        z >>= 7;
+        n++;
+    }
+    return n;
+}
+size_t no_uvarint_encode(uint32_t v, uint8_t *out) { /* :435-450 */
+    size_t n = 0;
+    while (v >= 0x80) {
+        out[n++] = (uint8_t)v | 0x80;
+        v >>= 7;
+    }
+    out[n++] = (uint8_t)v;
+    return n;
+}
+size_t no_varint_encode(int32_t v, uint8_t *out) { return no_uvarint_encode(zigzag32(v), out); }
+size_t no_varlong_encode(int64_t v, uint8_t *out) { /* :248-264 */
+    uint64_t z = zigzag64(v);
+    size_t n = 0;
+    while (z >= 0x80) {
+        out[n++] = (uint8_t)z | 0x80;
+        z >>= 7;
+    }
+    out[n++] = (uint8_t)z;
+    return n;
+}
+
+/* --------------------------------------------------------------- attributes */
+
+int no_compression(int16_t attributes, int *codec) { /* lib.rs:1685-1698 */
+    int c = attributes & 7;
+    if (c > 4) return NO_UNKNOWN_COMPRESSION;
+    *codec = c;
+    return NO_OK;
+}
+
+/* BatchAttribute::try_from(i16) then .compression(None).into(): lib.rs:1814-1850.
+ * Only bits 3 (timestamp type), 4, 5 and 6 survive the round trip. */
+int no_attributes_clear_compression(int16_t attributes, int16_t *out) {
+    int c;
+    int st = no_compression(attributes, &c);
+    if (st) return st;
+    *out = (int16_t)(attributes & (8 | 16 | 32 | 64));
+    return NO_OK;
+}
+
+/* ------------------------------------------------------------------ records */
+
+/* Octets::decode, record/codec.rs:65-76.  -1 is None; anything else is cast to
+ * usize and handed to Bytes::split_to, which panics past the end (so does any
+ * other negative length, which casts to a huge usize). */
+static int octets_decode(const uint8_t *buf, size_t len, size_t *pos, no_octets *out) {
+    int32_t n;
+    int st = no_varint_decode(buf, len, pos, &n);
+    if (st) return st;
+    if (n == -1) {
+        out->ptr = buf + *pos; /* None has no bytes; keep where they would start */
+        out->len = -1;
+        return NO_OK;
+    }
+    if (n < 0 || (size_t)n > len - *pos) return NO_PANIC;
+    out->ptr = buf + *pos;
+    out->len = n;
+    *pos += (size_t)n;
+    return NO_OK;
+}
+
+size_t no_octets_size(int64_t len) { /* codec.rs:34-45 */
+    if (len < 0) return no_varint_size(-1);
+    return no_varint_size((int32_t)len) + (size_t)len;
+}
+static size_t octets_size(const no_octets *o) { return no_octets_size(o->len); }
+
+static size_t octets_encode(const no_octets *o, uint8_t *out) { /* codec.rs:47-63 */
+    if (o->len < 0) return no_varint_encode(-1, out);
+    size_t n = no_varint_encode((int32_t)o->len, out);
+    memcpy(out + n, o->ptr, (size_t)o->len);
+    return n + (size_t)o->len;
+}
+
+void no_record_free(no_record *r) {
+    free(r->headers);
+    r->headers = NULL;
+    r->n_headers = 0;
+}
+
+/* Record::decode, record.rs:254-277, with VarIntSequence<Header>::decode
+ * (codec.rs:283-302) and Header::decode (header.rs:55-65) inlined. */
+int no_record_decode(const uint8_t *buf, size_t len, size_t *pos, no_record *out) {
+    int st;
+    memset(out, 0, sizeof *out);
+    if ((st = no_varint_decode(buf, len, pos, &out->length))) return st;
+    if (*pos >= len) return NO_PANIC; /* Buf::get_u8 on an empty buffer, record.rs:260 */
+    out->attributes = buf[(*pos)++];
+    if ((st = no_varlong_decode(buf, len, pos, &out->timestamp_delta))) return st;
+    if ((st = no_varint_decode(buf, len, pos, &out->offset_delta))) return st;
+    if ((st = octets_decode(buf, len, pos, &out->key))) return st;
+    if ((st = octets_decode(buf, len, pos, &out->value))) return st;
+    int32_t count;
+    if ((st = no_varint_decode(buf, len, pos, &count))) return st;
+    /* `length.0 as usize` then Vec::with_capacity: a negative count is a
+     * capacity-overflow panic (codec.rs:291-295) */
+    if (count < 0) return NO_PANIC;
+    /* A header is at least two bytes, so a count beyond the remaining bytes can
+     * only end in one of the errors below; walking finds which one first, as
+     * the reference does, without reserving count entries. */
+    size_t cap = 0;
+    for (int32_t i = 0; i < count; i++) {
+        no_header h;
+        if ((st = octets_decode(buf, len, pos, &h.key))) break;
+        if ((st = octets_decode(buf, len, pos, &h.value))) break;
+        if (out->n_headers == cap) {
+            cap = cap ? cap * 2 : 4;
+            out->headers = (no_header *)realloc(out->headers, cap * sizeof(no_header));
+        }
+        out->headers[out->n_headers++] = h;
+    }
+    if (st) {
+        no_record_free(out);
+        return st;
+    }
+    return NO_OK;
+}
+
+static size_t headers_size(const no_record *r) { /* codec.rs:248-262, header.rs:31-41 */
+    size_t n = no_varint_size((int32_t)r->n_headers);
+    for (size_t i = 0; i < r->n_headers; i++)
+        n += octets_size(&r->headers[i].key) + octets_size(&r->headers[i].value);
+    return n;
+}
+
+size_t no_record_body_size(const no_record *r) { /* record.rs:363-372 */
+    return 1 + no_varlong_size(r->timestamp_delta) + no_varint_size(r->offset_delta) +
+           octets_size(&r->key) + octets_size(&r->value) + headers_size(r);
+}
+
+size_t no_record_size(const no_record *r) { /* record.rs:200-212 */
+    return no_varint_size(r->length) + no_record_body_size(r);
+}
+
+size_t no_record_encode(const no_record *r, uint8_t *out) { /* record.rs:233-252 */
+    size_t n = no_varint_encode(r->length, out); /* the stored length, verbatim */
+    out[n++] = r->attributes;
+    n += no_varlong_encode(r->timestamp_delta, out + n);
+    n += no_varint_encode(r->offset_delta, out + n);
+    n += octets_encode(&r->key, out + n);
+    n += octets_encode(&r->value, out + n);
+    n += no_varint_encode((int32_t)r->n_headers, out + n); /* codec.rs:264-281 */
+    for (size_t i = 0; i < r->n_headers; i++) {            /* header.rs:43-53 */
+        n += octets_encode(&r->headers[i].key, out + n);
+        n += octets_encode(&r->headers[i].value, out + n);
+    }
+    return n;
+}
+
+size_t no_records_encode(const no_record *records, size_t n, uint8_t *out) { /* record.rs:214-231 */
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (out)
+            total += no_record_encode(&records[i], out + total);
+        else
+            total += no_record_size(&records[i]);
+    }
+    return total;
+}
+
+/* ----------------------------------------------------------- deflated batch */
+
+static uint64_t be64(const uint8_t *p) {
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) v = (v << 8) | p[i];
+    return v;
+}
+static uint32_t be32(const uint8_t *p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+static uint16_t be16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
+static void put64(uint8_t *p, uint64_t v) {
+    for (int i = 7; i >= 0; i--) {
+        p[i] = (uint8_t)v;
+        v >>= 8;
+    }
+}
+static void put32(uint8_t *p, uint32_t v) {
+    p[0] = (uint8_t)(v >> 24);
+    p[1] = (uint8_t)(v >> 16);
+    p[2] = (uint8_t)(v >> 8);
+    p[3] = (uint8_t)v;
+}
+static void put16(uint8_t *p, uint16_t v) {
+    p[0] = (uint8_t)(v >> 8);
+    p[1] = (uint8_t)v;
+}
+
+#define FIXED_BATCH_LENGTH 49 /* deflated.rs:486-508 */
+
+/* deflated::Batch::try_from(Bytes), deflated.rs:108-213, in the reference's
+ * order of checks. */
+int no_deflated_parse(const uint8_t *buf, size_t len, no_deflated_batch *out) {
+    memset(out, 0, sizeof *out);
+    /* :111-116 five try_get_* calls: 8 + 4 + 4 + 1 + 4 bytes */
+    if (len < 8) return NO_TRY_GET;
+    out->base_offset = (int64_t)be64(buf);
+    if (len < 12) return NO_TRY_GET;
+    out->batch_length = (int32_t)be32(buf + 8);
+    if (len < 16) return NO_TRY_GET;
+    out->partition_leader_epoch = (int32_t)be32(buf + 12);
+    if (len < 17) return NO_TRY_GET;
+    out->magic = (int8_t)buf[16];
+    if (len < 21) return NO_TRY_GET;
+    out->crc = be32(buf + 17);
+    size_t rem = len - 21;
+    /* :120-147 usize::try_from(batch_length) then three checked_sub (4, 1, 4) */
+    if (out->batch_length < 0) return NO_TRY_FROM_INT;
+    if (out->batch_length < 9) return NO_OVERFLOW;
+    size_t crc_data_size = (size_t)out->batch_length - 9;
+    if (crc_data_size > rem) return NO_OVERFLOW; /* :151-153 */
+    out->crc_computed = no_crc32c(buf + 21, crc_data_size); /* :155-166, mismatch only logs */
+    /* :168-175 eight more try_get_*: 2 + 4 + 8 + 8 + 8 + 2 + 4 + 4 = 40 bytes */
+    if (rem < 40) return NO_TRY_GET;
+    out->attributes = (int16_t)be16(buf + 21);
+    out->last_offset_delta = (int32_t)be32(buf + 23);
+    out->base_timestamp = (int64_t)be64(buf + 27);
+    out->max_timestamp = (int64_t)be64(buf + 35);
+    out->producer_id = (int64_t)be64(buf + 43);
+    out->producer_epoch = (int16_t)be16(buf + 51);
+    out->base_sequence = (int32_t)be32(buf + 53);
+    out->record_count = be32(buf + 57);
+    /* :177-190 */
+    if (out->batch_length < FIXED_BATCH_LENGTH) return NO_OVERFLOW;
+    size_t record_data_size = (size_t)out->batch_length - FIXED_BATCH_LENGTH;
+    if (record_data_size > len - 61) return NO_OVERFLOW;
+    out->record_data = buf + 61;
+    out->record_data_len = record_data_size;
+    return NO_OK;
+}
+
+size_t no_deflated_emit(const no_deflated_batch *b, uint8_t *out) { /* deflated.rs:84-106 */
+    put64(out, (uint64_t)b->base_offset);
+    put32(out + 8, (uint32_t)b->batch_length);
+    put32(out + 12, (uint32_t)b->partition_leader_epoch);
+    out[16] = (uint8_t)b->magic;
+    put32(out + 17, b->crc);
+    put16(out + 21, (uint16_t)b->attributes);
+    put32(out + 23, (uint32_t)b->last_offset_delta);
+    put64(out + 27, (uint64_t)b->base_timestamp);
+    put64(out + 35, (uint64_t)b->max_timestamp);
+    put64(out + 43, (uint64_t)b->producer_id);
+    put16(out + 51, (uint16_t)b->producer_epoch);
+    put32(out + 53, (uint32_t)b->base_sequence);
+    put32(out + 57, b->record_count);
+    if (b->record_data_len) memcpy(out + 61, b->record_data, b->record_data_len);
+    return 61 + b->record_data_len;
+}
+
+void no_records_free(no_record *records, size_t n) {
+    if (!records) return;
+    for (size_t i = 0; i < n; i++) no_record_free(&records[i]);
+    free(records);
+}
+
+/* Vec<Record>::try_from(deflated::Batch), deflated.rs:421-459.  Bytes after
+ * the last record are ignored (:437-442). */
+int no_inflate_records(const no_deflated_batch *b, no_record **records, size_t *n_records) {
+    int codec;
+    int st = no_compression(b->attributes, &codec);
+    *records = NULL;
+    *n_records = 0;
+    if (st) return st; /* :444-446 compression()? on the slow branch */
+    if (codec != 0) return NO_COMPRESSED;
+    /* Vec::with_capacity(record_count): a record is at least 7 bytes, so a
+     * count beyond the data can only fail; reserve what can succeed. */
+    size_t cap = b->record_count;
+    if (cap > b->record_data_len / 7 + 1) cap = b->record_data_len / 7 + 1;
+    no_record *v = (no_record *)calloc(cap ? cap : 1, sizeof(no_record));
+    size_t pos = 0, n = 0;
+    for (uint32_t i = 0; i < b->record_count; i++) {
+        no_record r;
+        st = no_record_decode(b->record_data, b->record_data_len, &pos, &r);
+        if (st) {
+            no_records_free(v, n);
+            return st;
+        }
+        if (n == cap) { /* unreachable for well-formed sizes; keeps the walk honest */
+            cap = cap * 2 + 1;
+            v = (no_record *)realloc(v, cap * sizeof(no_record));
+        }
+        v[n++] = r;
+    }
+    *records = v;
+    *n_records = n;
+    return NO_OK;
+}
+
+/* deflated::Batch::try_from(inflated::Batch), deflated.rs:392-409: record_count
+ * = records.len(); record_data = (&[Record]).encode(); batch_length = 49 +
+ * len (:302); crc over attributes..record_data (:318-326).  The inflated
+ * batch_length and crc are ignored. */
+int no_deflate(const no_deflated_batch *hdr, const no_record *records, size_t n, uint8_t *out,
+               size_t out_cap, size_t *out_len) {
+    int codec;
+    int st = no_compression(hdr->attributes, &codec);
+    if (st) return st;
+    if (codec != 0) return NO_COMPRESSED;
+    size_t data_len = no_records_encode(records, n, NULL);
+    if (61 + data_len > out_cap) return NO_CAPACITY;
+    if (FIXED_BATCH_LENGTH + data_len > 0x7fffffffu) return NO_TRY_FROM_INT; /* :302 */
+    no_deflated_batch b = *hdr;
+    b.record_count = (uint32_t)n;
+    b.batch_length = (int32_t)(FIXED_BATCH_LENGTH + data_len);
+    b.record_data = NULL;
+    b.record_data_len = 0;
+    b.crc = 0;
+    no_deflated_emit(&b, out);
+    no_records_encode(records, n, out + 61);
+    uint32_t crc = no_crc32c(out + 21, 40 + data_len);
+    put32(out + 17, crc);
+    *out_len = 61 + data_len;
+    return NO_OK;
+}
+
+/* inflated::Builder::size_in_bytes (inflated.rs:331-346) + Sequence::size_in_bytes
+ * (codec.rs:482-491, which sizes each record's prefix as an UNSIGNED varint of
+ * the body size via UnsignedVarInt::size_inclusive, varint.rs:536-543), and
+ * Builder::crc (inflated.rs:429-446), which serialises the records with the
+ * zigzag prefix actually written (record.rs:339-361). */
+int no_builder_batch_length_crc(const no_deflated_batch *hdr, const no_record *records, size_t n,
+                                int32_t *batch_length, uint32_t *crc) {
+    size_t size = 4 + 1 + 4 + 2 + 4 + 8 + 8 + 8 + 2 + 4 + 4;
+    size_t wire = 0;
+    for (size_t i = 0; i < n; i++) {
+        size_t body = no_record_body_size(&records[i]);
+        size += no_uvarint_size((uint32_t)body) + body;
+        wire += no_varint_size((int32_t)body) + body;
+    }
+    *batch_length = (int32_t)size;
+    uint8_t *buf = (uint8_t *)malloc(40 + wire);
+    put16(buf, (uint16_t)hdr->attributes);
+    put32(buf + 2, (uint32_t)hdr->last_offset_delta);
+    put64(buf + 6, (uint64_t)hdr->base_timestamp);
+    put64(buf + 14, (uint64_t)hdr->max_timestamp);
+    put64(buf + 22, (uint64_t)hdr->producer_id);
+    put16(buf + 30, (uint16_t)hdr->producer_epoch);
+    put32(buf + 32, (uint32_t)hdr->base_sequence);
+    put32(buf + 36, (uint32_t)n);
+    size_t p = 40;
+    for (size_t i = 0; i < n; i++) {
+        no_record r = records[i];
+        r.length = (int32_t)no_record_body_size(&records[i]);
+        p += no_record_encode(&r, buf + p);
+    }
+    *crc = no_crc32c(buf, p);
+    free(buf);
+    return NO_OK;
+}
+
+/* ------------------------------------------------------------------ framing */
+
+/* Batch::next_element_seed, de.rs:1059-1092: while bytes remain, read
+ * base_offset (i64) and batch_length (i32), Overflow if batch_length exceeds
+ * what is left, and hand 12 + batch_length bytes to the batch decoder.  A
+ * negative batch_length casts to a huge usize in BytesMut::with_capacity
+ * (:1074) and panics there. */
+int no_frame_split(const uint8_t *blob, size_t len, uint64_t *offsets, size_t cap, size_t *n) {
+    size_t pos = 0, k = 0;
+    while (pos < len) {
+        if (len - pos < 8) return NO_TRY_GET;
+        if (len - pos < 12) return NO_TRY_GET;
+        int32_t batch_length = (int32_t)be32(blob + pos + 8);
+        if (batch_length < 0) return NO_PANIC;
+        if ((size_t)batch_length > len - pos - 12) return NO_OVERFLOW;
+        if (k + 1 >= cap) return NO_CAPACITY;
+        offsets[k++] = pos;
+        pos += 12 + (size_t)batch_length;
+    }
+    if (k >= cap) return NO_CAPACITY;
+    offsets[k] = pos;
+    *n = k;
+    return NO_OK;
+}
+
+/* de.rs:701-720: flexible versions carry uvarint(len + 1), Overflow when the
+ * varint is 0; older versions a big-endian u32.  Length 0 means null. */
+int no_records_prefix_decode(const uint8_t *buf, size_t len, int flexible, size_t *pos,
+                             uint32_t *records_len, int *is_null) {
+    uint32_t v;
+    if (flexible) {
+        int st = no_uvarint_decode(buf, len, pos, &v);
+        if (st) return st;
+        if (v == 0) return NO_OVERFLOW;
+        v -= 1;
+    } else {
+        if (len - *pos < 4) return NO_TRY_GET;
+        v = be32(buf + *pos);
+        *pos += 4;
+    }
+    *records_len = v;
+    *is_null = (v == 0);
+    return NO_OK;
+}
+
+size_t no_records_prefix_encode(uint32_t records_len, int flexible, uint8_t *out) { /* ser.rs:484-489, 553-560 */
+    if (flexible) return no_uvarint_encode(records_len + 1, out);
+    put32(out, records_len);
+    return 4;
+}
+
+/* ------------------------------------------------------------------ columns */
+
+int no_decode_columns(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches,
+                      int by_value, no_columns *c, size_t rec_cap, size_t hdr_cap,
+                      size_t *n_records, size_t *n_headers) {
+    size_t nr = 0, nh = 0;
+    for (size_t b = 0; b < n_batches; b++) {
+        const uint8_t *buf = blob + batch_off[b];
+        size_t len = (size_t)(batch_off[b + 1] - batch_off[b]);
+        no_deflated_batch d;
+        int st = no_deflated_parse(buf, len, &d);
+        c->base_offset[b] = d.base_offset;
+        c->batch_length[b] = d.batch_length;
+        c->partition_leader_epoch[b] = d.partition_leader_epoch;
+        c->magic[b] = d.magic;
+        c->crc[b] = d.crc;
+        c->attributes[b] = d.attributes;
+        c->last_offset_delta[b] = d.last_offset_delta;
+        c->base_timestamp[b] = d.base_timestamp;
+        c->max_timestamp[b] = d.max_timestamp;
+        c->producer_id[b] = d.producer_id;
+        c->producer_epoch[b] = d.producer_epoch;
+        c->base_sequence[b] = d.base_sequence;
+        c->record_count[b] = d.record_count;
+        c->crc_computed[b] = d.crc_computed;
+        c->data_off[b] = batch_off[b] + 61;
+        c->data_len[b] = (uint32_t)d.record_data_len;
+        c->rec_base[b] = (uint32_t)nr;
+        c->hdr_base[b] = (uint32_t)nh;
+        c->hdr_count[b] = 0;
+        no_record *recs = NULL;
+        size_t n = 0;
+        if (st == NO_OK && by_value) {
+            /* inflated.rs:123-124: BatchAttribute::try_from before the records */
+            int16_t cleared;
+            st = no_attributes_clear_compression(d.attributes, &cleared);
+            if (st == NO_OK) {
+                int codec;
+                no_compression(d.attributes, &codec);
+                if (codec == 0) c->attributes[b] = cleared;
+            }
+        }
+        if (st == NO_OK) st = no_inflate_records(&d, &recs, &n);
+        c->status[b] = st;
+        if (st != NO_OK) {
+            c->record_count[b] = d.record_count;
+            continue;
+        }
+        size_t h0 = nh;
+        for (size_t i = 0; i < n; i++) {
+            const no_record *r = &recs[i];
+            if (nr >= rec_cap || nh + r->n_headers > hdr_cap) {
+                no_records_free(recs, n);
+                return NO_CAPACITY;
+            }
+            c->length[nr] = r->length;
+            c->rattributes[nr] = r->attributes;
+            c->timestamp_delta[nr] = r->timestamp_delta;
+            c->offset_delta[nr] = r->offset_delta;
+            /* a null span keeps the position right after its length varint */
+            c->key_len[nr] = (int32_t)r->key.len;
+            c->val_len[nr] = (int32_t)r->value.len;
+            c->key_off[nr] = (uint32_t)(r->key.ptr - d.record_data);
+            c->val_off[nr] = (uint32_t)(r->value.ptr - d.record_data);
+            c->rhdr_base[nr] = (uint32_t)nh;
+            c->rhdr_count[nr] = (int32_t)r->n_headers;
+            for (size_t j = 0; j < r->n_headers; j++) {
+                const no_header *h = &r->headers[j];
+                c->hkey_len[nh] = (int32_t)h->key.len;
+                c->hval_len[nh] = (int32_t)h->value.len;
+                c->hkey_off[nh] = (uint32_t)(h->key.ptr - d.record_data);
+                c->hval_off[nh] = (uint32_t)(h->value.ptr - d.record_data);
+                nh++;
+            }
+            nr++;
+        }
+        c->hdr_count[b] = (uint32_t)(nh - h0);
+        no_records_free(recs, n);
+    }
+    *n_records = nr;
+    *n_headers = nh;
+    return NO_OK;
+}
+
+static no_record *records_from_columns(const no_columns *c, size_t b, const uint8_t *base) {
+    size_t n = c->record_count[b];
+    no_record *recs = (no_record *)calloc(n ? n : 1, sizeof(no_record));
+    for (size_t i = 0; i < n; i++) {
+        size_t r = c->rec_base[b] + i;
+        no_record *x = &recs[i];
+        x->length = c->length[r];
+        x->attributes = c->rattributes[r];
+        x->timestamp_delta = c->timestamp_delta[r];
+        x->offset_delta = c->offset_delta[r];
+        x->key.len = c->key_len[r];
+        x->key.ptr = base + c->key_off[r];
+        x->value.len = c->val_len[r];
+        x->value.ptr = base + c->val_off[r];
+        x->n_headers = (size_t)c->rhdr_count[r];
+        x->headers = (no_header *)calloc(x->n_headers ? x->n_headers : 1, sizeof(no_header));
+        for (size_t j = 0; j < x->n_headers; j++) {
+            size_t h = c->rhdr_base[r] + j;
+            x->headers[j].key.len = c->hkey_len[h];
+            x->headers[j].key.ptr = base + c->hkey_off[h];
+            x->headers[j].value.len = c->hval_len[h];
+            x->headers[j].value.ptr = base + c->hval_off[h];
+        }
+    }
+    return recs;
+}
+
+static void header_from_columns(const no_columns *c, size_t b, no_deflated_batch *hdr) {
+    memset(hdr, 0, sizeof *hdr);
+    hdr->base_offset = c->base_offset[b];
+    hdr->partition_leader_epoch = c->partition_leader_epoch[b];
+    hdr->magic = c->magic[b];
+    hdr->attributes = c->attributes[b];
+    hdr->last_offset_delta = c->last_offset_delta[b];
+    hdr->base_timestamp = c->base_timestamp[b];
+    hdr->max_timestamp = c->max_timestamp[b];
+    hdr->producer_id = c->producer_id[b];
+    hdr->producer_epoch = c->producer_epoch[b];
+    hdr->base_sequence = c->base_sequence[b];
+}
+
+int no_encode_columns(const no_columns *c, size_t n_batches, const uint8_t *src,
+                      const uint64_t *src_data_off, uint8_t *out, size_t out_cap,
+                      uint64_t *out_off) {
+    size_t pos = 0;
+    for (size_t b = 0; b < n_batches; b++) {
+        out_off[b] = pos;
+        if (c->status[b] != NO_OK) continue;
+        size_t n = c->record_count[b];
+        no_record *recs = records_from_columns(c, b, src + src_data_off[b]);
+        no_deflated_batch hdr;
+        header_from_columns(c, b, &hdr);
+        size_t len = 0;
+        int st = no_deflate(&hdr, recs, n, out + pos, out_cap - pos, &len);
+        no_records_free(recs, n);
+        if (st) return st;
+        pos += len;
+    }
+    out_off[n_batches] = pos;
+    return NO_OK;
+}
+
+int no_builder_columns(const no_columns *c, size_t n_batches, const uint8_t *src,
+                       const uint64_t *src_data_off, int32_t *batch_length, uint32_t *crc) {
+    for (size_t b = 0; b < n_batches; b++) {
+        size_t n = c->record_count[b];
+        no_record *recs = records_from_columns(c, b, src + src_data_off[b]);
+        no_deflated_batch hdr;
+        header_from_columns(c, b, &hdr);
+        int st = no_builder_batch_length_crc(&hdr, recs, n, &batch_length[b], &crc[b]);
+        no_records_free(recs, n);
+        if (st) return st;
+    }
+    return NO_OK;
+}

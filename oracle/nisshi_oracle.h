@@ -1,0 +1,220 @@
+/*
+ * CPU restatement of the Kafka RecordBatch v2 codec of nisshi-sans-io (tansu).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is the parity checker for the HIP
+ * codec and the CPU baseline leg of bench.py.  Nothing in the shipped package
+ * may include, link or load it.
+ *
+ * The reference is Rust and cannot be built in this environment (no rustc or
+ * cargo), so this file restates its algorithm function by function; every
+ * function cites the reference lines it follows (paths relative to the
+ * reference tree).  It is pinned by the reference's own golden vectors and
+ * known-answer tests, transcribed as fixtures under tests/golden/.
+ *
+ * Error model.  The reference returns Result<_, Error> and panics on some
+ * malformed inputs; both are folded into one status code:
+ *   TRY_GET        Error::TryGet        (bytes::TryGetError, buffer under-run)
+ *   OVERFLOW       Error::Overflow
+ *   TRY_FROM_INT   Error::TryFromInt    (negative batch_length -> usize)
+ *   UNKNOWN_COMPRESSION  Error::UnknownCompressionType (attributes & 7 in 5..7)
+ *   PANIC          the reference panics (Bytes::split_to past the end,
+ *                  Buf::get_u8 on an empty buffer, Vec::with_capacity overflow)
+ *   COMPRESSED     attributes & 7 in 1..4: valid, but needs an inflator that
+ *                  is outside this path
+ */
+#ifndef NISSHI_ORACLE_H
+#define NISSHI_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    NO_OK = 0,
+    NO_TRY_GET = 1,
+    NO_OVERFLOW = 2,
+    NO_TRY_FROM_INT = 3,
+    NO_UNKNOWN_COMPRESSION = 4,
+    NO_PANIC = 5,
+    NO_COMPRESSED = 6,
+    NO_CAPACITY = 7
+};
+
+/* ---- CRC-32C ("Crc32Iscsi" of crc-fast 1.8.0; call sites deflated.rs:158-161,
+ * 322-325, inflated.rs:442-445).  Reflected polynomial 0x82F63B78, init and
+ * final xor 0xFFFFFFFF. */
+uint32_t no_crc32c(const uint8_t *data, size_t len);
+
+/* ---- varints (primitive/varint.rs) ---- */
+int no_varint_decode(const uint8_t *buf, size_t len, size_t *pos, int32_t *out);      /* :49-78 */
+int no_varlong_decode(const uint8_t *buf, size_t len, size_t *pos, int64_t *out);     /* :266-295 */
+size_t no_varint_size(int32_t v);                                                      /* :186-196 */
+size_t no_varlong_size(int64_t v);                                                     /* :379-389 */
+size_t no_uvarint_size(uint32_t v);                                                    /* :546-556 */
+size_t no_varint_encode(int32_t v, uint8_t *out);                                      /* :80-98 */
+size_t no_varlong_encode(int64_t v, uint8_t *out);                                     /* :248-264 */
+size_t no_uvarint_encode(uint32_t v, uint8_t *out);                                    /* :435-450 */
+int no_uvarint_decode(const uint8_t *buf, size_t len, size_t *pos, uint32_t *out);     /* :476-534 */
+
+/* ---- batch attributes (lib.rs:1643-1850) ---- */
+int no_compression(int16_t attributes, int *codec);          /* Compression::try_from :1685-1698 */
+int no_attributes_clear_compression(int16_t attributes, int16_t *out); /* BatchAttribute round trip :1814-1850 */
+
+/* ---- record types: the reference's in-memory shape (record.rs:172-198,
+ * header.rs:21-29).  Spans borrow the input buffer like Bytes::split_to. */
+typedef struct {
+    const uint8_t *ptr; /* first byte of the span (where it would start, when None) */
+    int64_t len;        /* -1 when the Option<Bytes> is None */
+} no_octets;
+
+typedef struct {
+    no_octets key;
+    no_octets value;
+} no_header;
+
+typedef struct {
+    int32_t length;
+    uint8_t attributes;
+    int64_t timestamp_delta;
+    int32_t offset_delta;
+    no_octets key;
+    no_octets value;
+    no_header *headers; /* heap vector, one per record, like Vec<Header> */
+    size_t n_headers;
+} no_record;
+
+void no_record_free(no_record *r);
+/* Record::decode, record.rs:254-277 */
+int no_record_decode(const uint8_t *buf, size_t len, size_t *pos, no_record *out);
+/* Record::size_in_bytes, record.rs:200-212 (uses the stored length verbatim) */
+size_t no_record_size(const no_record *r);
+/* Record::encode, record.rs:233-252 */
+size_t no_record_encode(const no_record *r, uint8_t *out);
+/* Octets::size_in_bytes, record/codec.rs:34-45; len < 0 is None */
+size_t no_octets_size(int64_t len);
+/* record::Builder::size_in_bytes, record.rs:363-372: body size, excluding the
+ * length prefix; this is the value Record::try_from(Builder) stores in length */
+size_t no_record_body_size(const no_record *r);
+
+/* ---- deflated::Batch (record/deflated.rs:67-82) ---- */
+typedef struct {
+    int64_t base_offset;
+    int32_t batch_length;
+    int32_t partition_leader_epoch;
+    int8_t magic;
+    uint32_t crc;
+    int16_t attributes;
+    int32_t last_offset_delta;
+    int64_t base_timestamp;
+    int64_t max_timestamp;
+    int64_t producer_id;
+    int16_t producer_epoch;
+    int32_t base_sequence;
+    uint32_t record_count;
+    const uint8_t *record_data;
+    size_t record_data_len;
+    uint32_t crc_computed; /* what the reference computes and only logs on mismatch */
+} no_deflated_batch;
+
+/* deflated::Batch::try_from(Bytes), deflated.rs:108-213 */
+int no_deflated_parse(const uint8_t *buf, size_t len, no_deflated_batch *out);
+/* From<deflated::Batch> for Bytes, deflated.rs:84-106; returns bytes written (61 + data) */
+size_t no_deflated_emit(const no_deflated_batch *b, uint8_t *out);
+/* Vec<Record>::try_from(deflated::Batch), deflated.rs:421-459 (Compression::None fast path).
+ * On success *records is a heap vector of record_count entries. */
+int no_inflate_records(const no_deflated_batch *b, no_record **records, size_t *n_records);
+void no_records_free(no_record *records, size_t n);
+/* (&[Record]).encode, record.rs:214-231; returns total bytes; out may be NULL to size */
+size_t no_records_encode(const no_record *records, size_t n, uint8_t *out);
+/* deflated::Batch::try_from(inflated::Batch), deflated.rs:392-409 with
+ * into_record_data :329-390 (None) and CrcData::into_batch :295-326.  The
+ * header fields are taken from hdr; batch_length, crc and record_count are
+ * recomputed.  out receives 61 + record_data bytes. */
+int no_deflate(const no_deflated_batch *hdr, const no_record *records, size_t n, uint8_t *out,
+               size_t out_cap, size_t *out_len);
+/* inflated::Builder::build batch_length and crc (inflated.rs:331-346, 429-481),
+ * including the unsigned-varint sizing of the per-record length prefix
+ * (codec.rs:486-490) */
+int no_builder_batch_length_crc(const no_deflated_batch *hdr, const no_record *records, size_t n,
+                                int32_t *batch_length, uint32_t *crc);
+
+/* ---- records-blob framing (de.rs:1056-1093): split a records blob into batches.
+ * offsets receives n+1 entries. */
+int no_frame_split(const uint8_t *blob, size_t len, uint64_t *offsets, size_t cap, size_t *n);
+/* records field length prefix (de.rs:701-720, ser.rs:521-574) */
+int no_records_prefix_decode(const uint8_t *buf, size_t len, int flexible, size_t *pos,
+                             uint32_t *records_len, int *is_null);
+size_t no_records_prefix_encode(uint32_t records_len, int flexible, uint8_t *out);
+
+/* ---- column (SoA) form used to compare with the HIP codec ---- */
+typedef struct {
+    /* per batch, n_batches entries */
+    int64_t *base_offset;
+    int32_t *batch_length;
+    int32_t *partition_leader_epoch;
+    int8_t *magic;
+    uint32_t *crc;
+    int16_t *attributes;
+    int32_t *last_offset_delta;
+    int64_t *base_timestamp;
+    int64_t *max_timestamp;
+    int64_t *producer_id;
+    int16_t *producer_epoch;
+    int32_t *base_sequence;
+    uint32_t *record_count;
+    uint32_t *crc_computed;
+    uint64_t *data_off; /* absolute offset of record_data in the blob */
+    uint32_t *data_len;
+    uint32_t *rec_base; /* index of the batch's first record in the record columns */
+    uint32_t *hdr_base; /* index of the batch's first header in the header columns */
+    uint32_t *hdr_count;
+    int32_t *status;
+    /* per record */
+    int32_t *length;
+    uint8_t *rattributes;
+    int64_t *timestamp_delta;
+    int32_t *offset_delta;
+    uint32_t *key_off; /* offsets are relative to the batch's record_data */
+    int32_t *key_len;  /* -1 = null */
+    uint32_t *val_off;
+    int32_t *val_len;
+    uint32_t *rhdr_base; /* absolute index into the header columns */
+    int32_t *rhdr_count;
+    /* per header */
+    uint32_t *hkey_off;
+    int32_t *hkey_len;
+    uint32_t *hval_off;
+    int32_t *hval_len;
+} no_columns;
+
+/* Decode every batch of a blob into columns.  batch_off has n_batches + 1
+ * entries.  A batch that fails gets its status and contributes no records.
+ * by_value != 0 normalises attributes as inflated::Batch::try_from(deflated::Batch)
+ * does (inflated.rs:123-140); 0 keeps them verbatim (inflated.rs:161-177).
+ * rec_cap / hdr_cap bound the column arrays; returns NO_CAPACITY when exceeded. */
+int no_decode_columns(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches,
+                      int by_value, no_columns *cols, size_t rec_cap, size_t hdr_cap,
+                      size_t *n_records, size_t *n_headers);
+
+/* Re-encode batches from columns (deflated::Batch::try_from(inflated::Batch) over a
+ * whole frame, deflated.rs:52-63).  Payload spans are read from src at
+ * src_data_off[b] + offset.  Batches whose status is not OK are skipped (zero
+ * bytes).  out_off receives n_batches + 1 entries. */
+int no_encode_columns(const no_columns *cols, size_t n_batches, const uint8_t *src,
+                      const uint64_t *src_data_off, uint8_t *out, size_t out_cap,
+                      uint64_t *out_off);
+
+/* inflated::Builder::build over columns: per batch, the batch_length and crc an
+ * inflated::Batch built from these records would carry (inflated.rs:448-481).
+ * Each record's length is recomputed from its body, as Record::try_from(Builder)
+ * does (record.rs:298-314). */
+int no_builder_columns(const no_columns *cols, size_t n_batches, const uint8_t *src,
+                       const uint64_t *src_data_off, int32_t *batch_length, uint32_t *crc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,154 @@
+"""ctypes binding of the CPU restatement in oracle/ (test infrastructure only)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from tansu_amd import columns as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libnisshi_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libnisshi_oracle.so"])
+
+
+def _load():
+    src = os.path.join(ORACLE_DIR, "nisshi_oracle.c")
+    if not os.path.exists(LIB_PATH) or (
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(LIB_PATH)):
+        build()
+    lib = ctypes.CDLL(LIB_PATH)
+    u8p = ctypes.c_char_p
+    sz = ctypes.c_size_t
+    lib.no_crc32c.restype = ctypes.c_uint32
+    lib.no_crc32c.argtypes = [u8p, sz]
+    for name in ("no_varint_size",):
+        getattr(lib, name).restype = sz
+        getattr(lib, name).argtypes = [ctypes.c_int32]
+    lib.no_varlong_size.restype = sz
+    lib.no_varlong_size.argtypes = [ctypes.c_int64]
+    lib.no_uvarint_size.restype = sz
+    lib.no_uvarint_size.argtypes = [ctypes.c_uint32]
+    lib.no_octets_size.restype = sz
+    lib.no_octets_size.argtypes = [ctypes.c_int64]
+    lib.no_varint_encode.restype = sz
+    lib.no_varint_encode.argtypes = [ctypes.c_int32, ctypes.c_void_p]
+    lib.no_varlong_encode.restype = sz
+    lib.no_varlong_encode.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+    lib.no_uvarint_encode.restype = sz
+    lib.no_uvarint_encode.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
+    lib.no_varint_decode.argtypes = [u8p, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int32)]
+    lib.no_varlong_decode.argtypes = [u8p, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int64)]
+    lib.no_uvarint_decode.argtypes = [u8p, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32)]
+    lib.no_compression.argtypes = [ctypes.c_int16, ctypes.POINTER(ctypes.c_int)]
+    lib.no_attributes_clear_compression.argtypes = [ctypes.c_int16, ctypes.POINTER(ctypes.c_int16)]
+    lib.no_frame_split.argtypes = [u8p, sz, ctypes.c_void_p, sz, ctypes.POINTER(sz)]
+    lib.no_records_prefix_decode.argtypes = [u8p, sz, ctypes.c_int, ctypes.POINTER(sz),
+                                             ctypes.POINTER(ctypes.c_uint32),
+                                             ctypes.POINTER(ctypes.c_int)]
+    lib.no_records_prefix_encode.restype = sz
+    lib.no_records_prefix_encode.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    lib.no_decode_columns.argtypes = [ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_int,
+                                      ctypes.POINTER(C.CColumns), sz, sz,
+                                      ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.no_encode_columns.argtypes = [ctypes.POINTER(C.CColumns), sz, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_void_p]
+    lib.no_builder_columns.argtypes = [ctypes.POINTER(C.CColumns), sz, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+LIB = _load()
+
+
+def crc32c(data: bytes) -> int:
+    return LIB.no_crc32c(bytes(data), len(data))
+
+
+def varint_decode(data: bytes, kind="i32"):
+    """Returns (status, value, consumed)."""
+    pos = ctypes.c_size_t(0)
+    data = bytes(data)
+    if kind == "i32":
+        out = ctypes.c_int32()
+        st = LIB.no_varint_decode(data, len(data), ctypes.byref(pos), ctypes.byref(out))
+    elif kind == "i64":
+        out = ctypes.c_int64()
+        st = LIB.no_varlong_decode(data, len(data), ctypes.byref(pos), ctypes.byref(out))
+    else:
+        out = ctypes.c_uint32()
+        st = LIB.no_uvarint_decode(data, len(data), ctypes.byref(pos), ctypes.byref(out))
+    return st, out.value, pos.value
+
+
+def varint_encode(v: int, kind="i32") -> bytes:
+    buf = ctypes.create_string_buffer(16)
+    fn = {"i32": LIB.no_varint_encode, "i64": LIB.no_varlong_encode, "u32": LIB.no_uvarint_encode}[kind]
+    n = fn(v, buf)
+    return buf.raw[:n]
+
+
+def varint_size(v: int, kind="i32") -> int:
+    fn = {"i32": LIB.no_varint_size, "i64": LIB.no_varlong_size, "u32": LIB.no_uvarint_size}[kind]
+    return fn(v)
+
+
+def frame_split(blob: bytes):
+    """Returns (status, offsets np.uint64[n+1])."""
+    cap = len(blob) // 12 + 2
+    off = np.zeros(cap, dtype=np.uint64)
+    n = ctypes.c_size_t(0)
+    st = LIB.no_frame_split(bytes(blob), len(blob), off.ctypes.data, cap, ctypes.byref(n))
+    return st, off[:n.value + 1].copy()
+
+
+def decode_columns(blob, batch_off, by_value=True, rec_cap=None, hdr_cap=None):
+    """Decode a blob of batches.  Returns (status, cols, n_records, n_headers)."""
+    blob = np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+    batch_off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+    n_b = len(batch_off) - 1
+    if rec_cap is None:
+        rec_cap = len(blob) // 7 + 1
+    if hdr_cap is None:
+        hdr_cap = len(blob) // 2 + 1
+    cols = C.alloc_host(n_b, rec_cap, hdr_cap)
+    cc = C.as_c(cols)
+    nr, nh = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    st = LIB.no_decode_columns(blob.ctypes.data, batch_off.ctypes.data, n_b, int(by_value),
+                               ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(nr),
+                               ctypes.byref(nh))
+    return st, C.trim(cols, n_b, nr.value, nh.value), nr.value, nh.value
+
+
+def encode_columns(cols, n_batches, src, src_data_off, out_cap=None):
+    """Re-encode batches.  Returns (status, out bytes, out_off np.uint64[n+1])."""
+    src = np.frombuffer(bytes(src), dtype=np.uint8) if not isinstance(src, np.ndarray) else src
+    src_data_off = np.ascontiguousarray(src_data_off, dtype=np.uint64)
+    if out_cap is None:
+        out_cap = len(src) * 2 + 128 * n_batches + 1024
+    out = np.zeros(out_cap, dtype=np.uint8)
+    out_off = np.zeros(n_batches + 1, dtype=np.uint64)
+    cc = C.as_c(cols)
+    st = LIB.no_encode_columns(ctypes.byref(cc), n_batches, src.ctypes.data,
+                               src_data_off.ctypes.data, out.ctypes.data, out_cap,
+                               out_off.ctypes.data)
+    return st, out[:int(out_off[n_batches])].tobytes(), out_off
+
+
+def builder_columns(cols, n_batches, src, src_data_off):
+    """inflated::Builder::build batch_length and crc per batch (records' length
+    is recomputed from the body, as Record::try_from(Builder) does)."""
+    src = np.frombuffer(bytes(src), dtype=np.uint8) if not isinstance(src, np.ndarray) else src
+    src_data_off = np.ascontiguousarray(src_data_off, dtype=np.uint64)
+    bl = np.zeros(max(n_batches, 1), dtype=np.int32)
+    crc = np.zeros(max(n_batches, 1), dtype=np.uint32)
+    cc = C.as_c(cols)
+    st = LIB.no_builder_columns(ctypes.byref(cc), n_batches, src.ctypes.data,
+                                src_data_off.ctypes.data, bl.ctypes.data, crc.ctypes.data)
+    return st, bl[:n_batches], crc[:n_batches]
