@@ -1,0 +1,170 @@
+/*
+ * nisshi_hip.h: C ABI of the MI355X (gfx950) Kafka RecordBatch v2 codec.
+ *
+ * This is the boundary a `nisshi-hip` FFI crate binds: plain pointers and
+ * sizes, no C++ or torch types.  It replaces, for uncompressed batches, the
+ * record path of nisshi-sans-io (file:line below are paths in the tansu /
+ * nisshi reference tree):
+ *
+ *   deflated::Batch::try_from(Bytes)                src/record/deflated.rs:108-213
+ *   Vec<Record>::try_from(deflated::Batch)          src/record/deflated.rs:421-459
+ *   inflated::Batch::try_from(deflated::Batch)      src/record/inflated.rs:114-150
+ *   inflated::Batch::try_from(&deflated::Batch)     src/record/inflated.rs:152-187
+ *   inflated::Frame::try_from(deflated::Frame)      src/record/inflated.rs:34-62
+ *   deflated::Batch::try_from(inflated::Batch)      src/record/deflated.rs:392-409
+ *   deflated::Frame::try_from(inflated::Frame)      src/record/deflated.rs:52-63
+ *   From<deflated::Batch> for Bytes                 src/record/deflated.rs:84-106
+ *   records-blob framing                            src/de.rs:701-720, 1056-1093; src/ser.rs:484-489, 521-574
+ *
+ * Decoded batches are columns (one array per field), not Vec<Record>.  Span
+ * offsets are relative to the batch's record_data, mirroring the zero-copy
+ * Bytes::split_to slices of the reference (src/record/codec.rs:65-76): a null
+ * Option<Bytes> has length -1 and the offset where its bytes would start.
+ *
+ * Threading: a context may be used by one thread at a time; create one per
+ * thread (or guard it).  Calls enqueue work on the given HIP stream.
+ */
+#ifndef NISSHI_HIP_H
+#define NISSHI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-batch and per-call status.  The first seven mirror the outcomes of the
+ * reference: its Error variants (src/lib.rs:328-366) and its panics. */
+enum {
+    NISSHI_OK = 0,
+    NISSHI_TRY_GET = 1,             /* Error::TryGet: buffer under-run */
+    NISSHI_OVERFLOW = 2,            /* Error::Overflow */
+    NISSHI_TRY_FROM_INT = 3,        /* Error::TryFromInt: negative batch_length */
+    NISSHI_UNKNOWN_COMPRESSION = 4, /* Error::UnknownCompressionType: attributes & 7 in 5..7 */
+    NISSHI_MALFORMED = 5,           /* the reference panics on this input */
+    NISSHI_COMPRESSED = 6,          /* attributes & 7 in 1..4: not decoded here */
+    NISSHI_CAPACITY = 7,            /* an output array is too small */
+    NISSHI_DEVICE_ERROR = 8,        /* a HIP call failed; see nisshi_hip_last_error */
+    NISSHI_INVALID_ARGUMENT = 9
+};
+
+/* One pointer per column.  For the *_dev entry points these are device
+ * pointers; for the host entry points host pointers.  Field order is ABI. */
+typedef struct nisshi_columns {
+    /* per batch: the 13 fields of the 61-byte header (deflated.rs:67-82) */
+    int64_t *base_offset;
+    int32_t *batch_length;
+    int32_t *partition_leader_epoch;
+    int8_t *magic;
+    uint32_t *crc; /* the wire value, also when it does not match */
+    int16_t *attributes;
+    int32_t *last_offset_delta;
+    int64_t *base_timestamp;
+    int64_t *max_timestamp;
+    int64_t *producer_id;
+    int16_t *producer_epoch;
+    int32_t *base_sequence;
+    uint32_t *record_count;
+    /* per batch: derived */
+    uint32_t *crc_computed; /* CRC-32C over attributes..end of batch (deflated.rs:155-166) */
+    uint64_t *data_off;     /* offset of record_data in the blob */
+    uint32_t *data_len;
+    uint32_t *rec_base;  /* index of the batch's first record in the record columns */
+    uint32_t *hdr_base;  /* index of the batch's first header in the header columns */
+    uint32_t *hdr_count; /* headers in the batch */
+    int32_t *status;
+    /* per record (record.rs:172-198) */
+    int32_t *length;
+    uint8_t *rattributes;
+    int64_t *timestamp_delta;
+    int32_t *offset_delta;
+    uint32_t *key_off;
+    int32_t *key_len;
+    uint32_t *val_off;
+    int32_t *val_len;
+    uint32_t *rhdr_base; /* index of the record's first header in the header columns */
+    int32_t *rhdr_count;
+    /* per header (header.rs:21-29) */
+    uint32_t *hkey_off;
+    int32_t *hkey_len;
+    uint32_t *hval_off;
+    int32_t *hval_len;
+} nisshi_columns;
+
+typedef struct nisshi_totals {
+    uint64_t n_records;  /* record slots used (a failed batch may leave its slots unused) */
+    uint64_t n_headers;  /* header slots used */
+    uint32_t n_failed;   /* batches whose status is not NISSHI_OK */
+    uint32_t n_exact;    /* batches that needed the sequential walk (length disagreed with the fields) */
+    uint64_t out_bytes;  /* encode: bytes written */
+} nisshi_totals;
+
+typedef struct nisshi_hip_ctx nisshi_hip_ctx;
+
+/* Create a context on a HIP device; fails with NISSHI_DEVICE_ERROR when no
+ * usable gfx950 device is present.  There is no CPU fallback. */
+int nisshi_hip_ctx_create(int device, nisshi_hip_ctx **ctx);
+void nisshi_hip_ctx_destroy(nisshi_hip_ctx *ctx);
+const char *nisshi_hip_status_str(int status);
+const char *nisshi_hip_last_error(const nisshi_hip_ctx *ctx);
+
+/* Host-side framing of a records blob (de.rs:1056-1093): writes the start of
+ * every batch plus the end of the last one (n + 1 entries). */
+int nisshi_frame_split(const uint8_t *blob, uint64_t len, uint64_t *batch_off, uint64_t cap,
+                       uint64_t *n_batches);
+/* records field length prefix: u32 big-endian, or uvarint(len + 1) in flexible
+ * versions; length 0 is a null field (de.rs:701-720, ser.rs:484-489, 553-560) */
+int nisshi_records_prefix_decode(const uint8_t *buf, uint64_t len, int flexible, uint64_t *pos,
+                                 uint32_t *records_len, int *is_null);
+uint64_t nisshi_records_prefix_encode(uint32_t records_len, int flexible, uint8_t *out);
+
+/* Sum of record_count over the batches whose header is well formed and
+ * uncompressed: the record capacity a decode of this blob needs.  Device
+ * pointers; synchronises the stream. */
+int nisshi_hip_count_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
+                         const uint64_t *d_batch_off, uint32_t n_batches, uint64_t *n_records,
+                         void *stream);
+
+/* Decode n_batches batches resident in device memory into device columns.
+ * d_batch_off has n_batches + 1 entries.  by_value != 0 clears the compression
+ * bits of attributes and drops unknown bits as inflated::Batch::try_from(
+ * deflated::Batch) does; 0 keeps attributes verbatim (the by-reference
+ * conversion).  With totals == NULL the call only enqueues work; otherwise it
+ * waits for the stream and fills *totals.  A batch that fails leaves its
+ * status and no valid records; the call still returns NISSHI_OK. */
+int nisshi_hip_decode_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
+                          const uint64_t *d_batch_off, uint32_t n_batches, int by_value,
+                          const nisshi_columns *d_cols, uint64_t rec_cap, uint64_t hdr_cap,
+                          nisshi_totals *totals, void *stream);
+
+/* Encode batches from device columns (deflated::Batch::try_from(inflated::Batch)
+ * over a frame): record_count, batch_length and crc are recomputed, the length
+ * of every record is emitted as stored.  Spans of batch b are read from d_src at
+ * d_src_data_off[b] + offset.  d_out_off receives n_batches + 1 offsets into
+ * d_out.  Batches whose status is not NISSHI_OK are skipped. */
+int nisshi_hip_encode_dev(nisshi_hip_ctx *ctx, const nisshi_columns *d_cols, uint32_t n_batches,
+                          const uint8_t *d_src, const uint64_t *d_src_data_off, uint8_t *d_out,
+                          uint64_t out_cap, uint64_t *d_out_off, nisshi_totals *totals,
+                          void *stream);
+
+/* Host-buffer forms: copy the blob to the device, decode, copy the columns
+ * back.  The library owns the device buffers.  cols holds host pointers sized
+ * rec_cap / hdr_cap. */
+int nisshi_hip_decode(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
+                      const uint64_t *batch_off, uint32_t n_batches, int by_value,
+                      const nisshi_columns *cols, uint64_t rec_cap, uint64_t hdr_cap,
+                      nisshi_totals *totals);
+int nisshi_hip_encode(nisshi_hip_ctx *ctx, const nisshi_columns *cols, uint32_t n_batches,
+                      uint64_t n_records, uint64_t n_headers, const uint8_t *src, uint64_t src_len,
+                      const uint64_t *src_data_off, uint8_t *out, uint64_t out_cap,
+                      uint64_t *out_off, nisshi_totals *totals);
+
+/* CRC-32C of a device buffer (crc-fast "Crc32Iscsi", used at deflated.rs:158-161). */
+int nisshi_hip_crc32c_dev(nisshi_hip_ctx *ctx, const uint8_t *d_data, uint64_t len, uint32_t *crc,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

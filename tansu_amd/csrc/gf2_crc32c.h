@@ -1,0 +1,200 @@
+// CRC-32C arithmetic for gfx950 without lookup tables in the streaming loop.
+//
+// CRC-32C ("Crc32Iscsi" in the reference, nisshi-sans-io/src/record/deflated.rs:158-161)
+// is the remainder of the message polynomial modulo
+//   P(x) = x^32 + x^28 + x^27 + x^26 + x^25 + x^23 + x^22 + x^20 + x^19 + x^18
+//        + x^14 + x^13 + x^11 + x^10 + x^9 + x^8 + x^6 + 1
+// with bit-reflected I/O, init and final xor 0xFFFFFFFF.
+//
+// Representation used throughout: a 32-bit residue has bit i = coefficient of
+// x^(31-i) (the reflected register), and message bytes loaded as little-endian
+// words put stream bit s at word bit s, so a LOWER bit index is a HIGHER degree
+// and multiplying by x^k is a logical right shift by k.
+//
+// The streaming loop keeps a 8192-bit accumulator row per wavefront (64 lanes x
+// 16 bytes, exactly one coalesced dwordx4 load) and folds it onto the next row
+// with a sparse congruence found by exhaustive search
+// (tools/crc32c_sparse_search.c):
+//   x^8192 == x^62 + x^59 + x^48 + x^43 + x^32 + x^27 + x^21 + x^5 + 1  (mod P)
+// so one fold is nine shifted copies of the row XORed together: funnel shifts
+// (v_alignbit_b32) and v_xor3, about 3.4 vector ops per byte and no LDS traffic,
+// where a table-driven CRC needs one LDS lookup per byte.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nisshi {
+
+constexpr uint32_t kPolyReflected = 0x82F63B78u;
+constexpr uint32_t kOne = 0x80000000u;  // x^0
+constexpr uint32_t kX = 0x40000000u;    // x^1
+constexpr int kRowBytes = 1024;         // one accumulator row: 64 lanes x 16 bytes
+constexpr int kChunkRows = 64;          // rows per CRC work item
+constexpr int kChunkBytes = kRowBytes * kChunkRows;
+
+__host__ __device__ inline uint32_t gf_mulx(uint32_t a) {
+    return (a >> 1) ^ (kPolyReflected & (0u - (a & 1u)));
+}
+
+// a * b mod P
+__host__ __device__ inline uint32_t gf_mulmod(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        r ^= a & (0u - (b >> 31));
+        b <<= 1;
+        a = gf_mulx(a);
+    }
+    return r;
+}
+
+// v * x^32 mod P: one word step of the bitwise CRC
+__host__ __device__ inline uint32_t gf_shift32(uint32_t v) {
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) v = gf_mulx(v);
+    return v;
+}
+
+// Constants in device memory, built once per context on the host.
+struct CrcTables {
+    uint32_t inv8[kRowBytes];   // x^(-8k): undoes k trailing zero bytes
+    uint32_t lane_weight[64];   // x^(128 * (63 - lane)): position of a lane's 16 bytes in the row
+    uint32_t pow8[40];          // x^(8 * 2^k)
+    uint32_t chunk_weight;      // x^(8 * kChunkBytes)
+};
+
+inline uint32_t host_xpow(uint64_t n) {  // x^n mod P
+    uint32_t r = kOne, base = kX;
+    while (n) {
+        if (n & 1) r = gf_mulmod(r, base);
+        base = gf_mulmod(base, base);
+        n >>= 1;
+    }
+    return r;
+}
+
+inline void build_crc_tables(CrcTables *t) {
+    // P = x * Q + 1, so x^-1 = Q: drop the constant term of P and divide by x.
+    uint32_t xinv = ((kOne ^ kPolyReflected) << 1) | 1u;
+    uint32_t xinv8 = kOne;
+    for (int i = 0; i < 8; i++) xinv8 = gf_mulmod(xinv8, xinv);
+    t->inv8[0] = kOne;
+    for (int k = 1; k < kRowBytes; k++) t->inv8[k] = gf_mulmod(t->inv8[k - 1], xinv8);
+    for (int l = 0; l < 64; l++) t->lane_weight[l] = host_xpow(128ull * (63 - l));
+    uint32_t p = host_xpow(8);
+    for (int k = 0; k < 40; k++) {
+        t->pow8[k] = p;
+        p = gf_mulmod(p, p);
+    }
+    t->chunk_weight = host_xpow(8ull * kChunkBytes);
+}
+
+#if defined(__HIPCC__)
+
+// x^(8n) mod P from the table of x^(8 * 2^k)
+__device__ inline uint32_t gf_xpow8(const CrcTables *t, uint64_t n) {
+    uint32_t r = kOne;
+    for (int k = 0; n; k++, n >>= 1)
+        if (n & 1) r = gf_mulmod(r, t->pow8[k]);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t fsh(uint32_t hi, uint32_t lo, int r) {
+    return __builtin_amdgcn_alignbit(hi, lo, r);  // ({hi,lo} >> r)[31:0]
+}
+
+// One fold: acc = next ^ (acc * x^8192 mod Q), Q = x^8192 + T.  The row is a
+// little-endian 8192-bit number spread over the wave; multiplying by x^t is a
+// right shift of the whole row by t bits.  The t low bits that fall off the
+// bottom belong to the top of the row and are folded once more; for t < 64 they
+// all come from lane 0's first two words and land in lane 63's last two.
+__device__ __forceinline__ void crc_fold_row(uint32_t (&a)[4], const uint32_t (&nx)[4],
+                                             int lane) {
+    uint64_t low = ((uint64_t)__builtin_amdgcn_readfirstlane(a[1]) << 32) |
+                   __builtin_amdgcn_readfirstlane(a[0]);
+    uint64_t wrap = (low << 2) ^ (low << 5) ^ (low << 16) ^ (low << 21) ^ (low << 32) ^
+                    (low << 37) ^ (low << 43) ^ (low << 59);  // 64 - t for every t > 0
+    uint32_t top = lane == 63 ? 0xFFFFFFFFu : 0u;
+    a[2] ^= (uint32_t)wrap & top;
+    a[3] ^= (uint32_t)(wrap >> 32) & top;
+    uint32_t n0 = __shfl_down(a[0], 1, 64);
+    uint32_t n1 = __shfl_down(a[1], 1, 64);
+    n0 &= ~top;  // nothing above lane 63
+    n1 &= ~top;
+    uint32_t w[6] = {a[0], a[1], a[2], a[3], n0, n1};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t s = nx[i] ^ w[i] ^ w[i + 1];                 // x^0 and x^32
+        s ^= fsh(w[i + 1], w[i], 5) ^ fsh(w[i + 1], w[i], 21);
+        s ^= fsh(w[i + 1], w[i], 27) ^ fsh(w[i + 2], w[i + 1], 11);  // x^27, x^43
+        s ^= fsh(w[i + 2], w[i + 1], 16) ^ fsh(w[i + 2], w[i + 1], 27);  // x^48, x^59
+        s ^= fsh(w[i + 2], w[i + 1], 30);                     // x^62
+        a[i] = s;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v ^= __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Collapse the accumulator row to the 32-bit value (row polynomial) * x^32 mod P.
+__device__ inline uint32_t crc_row_residue(const uint32_t (&a)[4], int lane, const CrcTables *t) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c = gf_shift32(c ^ a[i]);
+    return wave_xor(gf_mulmod(c, t->lane_weight[lane]));
+}
+
+// Byte mask of a little-endian word at absolute address `addr`: keep the bytes in [lo, hi).
+__device__ __forceinline__ uint32_t byte_mask(uint64_t addr, uint64_t lo, uint64_t hi) {
+    uint32_t m = 0xFFFFFFFFu;
+    if (lo > addr) m = lo >= addr + 4 ? 0u : m << (8 * (uint32_t)(lo - addr));
+    if (hi < addr + 4) m = hi <= addr ? 0u : m & (0xFFFFFFFFu >> (8 * (uint32_t)(addr + 4 - hi)));
+    return m;
+}
+
+// Raw remainder of the bytes [lo, hi) of `base` that fall in rows [row0, row1) of
+// the row grid anchored at `grid` (16-byte aligned absolute offset, grid <= lo).
+// `first4` is the offset of the first message byte: the four bytes from there
+// are complemented, which is the CRC's 0xFFFFFFFF initial value.  The result is
+// (bytes as a polynomial, zero padded to the end of the last row) * x^32 mod P.
+__device__ inline uint32_t crc_rows(const uint8_t *base, uint64_t grid, uint64_t lo, uint64_t hi,
+                                    uint64_t first4, uint32_t row0, uint32_t row1, int lane,
+                                    const CrcTables *t) {
+    uint32_t acc[4] = {0, 0, 0, 0};
+    bool started = false;
+    for (uint32_t r = row0; r < row1; r++) {
+        uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
+        uint32_t nx[4] = {0, 0, 0, 0};
+        if (addr + 16 > lo && addr < hi) {
+            uint4 v = *reinterpret_cast<const uint4 *>(base + addr);
+            nx[0] = v.x;
+            nx[1] = v.y;
+            nx[2] = v.z;
+            nx[3] = v.w;
+            if (addr < lo || addr + 16 > hi) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) nx[i] &= byte_mask(addr + 4 * i, lo, hi);
+            }
+        }
+        // the complement covers four bytes even when the message is shorter
+        if (addr + 16 > first4 && addr < first4 + 4) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) nx[i] ^= byte_mask(addr + 4 * i, first4, first4 + 4);
+        }
+        if (started) {
+            crc_fold_row(acc, nx, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = nx[i];
+            started = true;
+        }
+    }
+    return crc_row_residue(acc, lane, t);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace nisshi

@@ -1,0 +1,149 @@
+// Device-side readers for the Kafka record wire format: byte windows over
+// global memory, zigzag varints and the per-record field walk.  Semantics follow
+// nisshi-sans-io (paths in the reference tree):
+//   VarInt::decode / LongVarInt::decode   src/primitive/varint.rs:49-78, 266-295
+//   Octets::decode                         src/record/codec.rs:65-76
+//   VarIntSequence<Header>::decode         src/record/codec.rs:283-302
+//   Header::decode                         src/record/header.rs:55-65
+//   Record::decode                         src/record.rs:254-277
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nisshi_hip.h"
+
+namespace nisshi {
+
+// Eight bytes starting at data[pos], assembled from aligned dword loads so that
+// no load touches a 4-byte word that holds no byte of [data, data + len): an
+// aligned word that contains a valid byte lies in that byte's page.  Bytes past
+// `len` read as whatever follows or zero and must be ignored by the caller.
+__device__ __forceinline__ uint64_t window64(const uint8_t *data, uint32_t pos, uint32_t len) {
+    uintptr_t p = reinterpret_cast<uintptr_t>(data) + pos;
+    uintptr_t last = (reinterpret_cast<uintptr_t>(data) + len - 1) & ~uintptr_t(3);
+    uintptr_t a0 = p & ~uintptr_t(3);
+    a0 = a0 <= last ? a0 : last;
+    uintptr_t a1 = a0 + 4 <= last ? a0 + 4 : last;
+    uintptr_t a2 = a0 + 8 <= last ? a0 + 8 : last;
+    uint32_t d0 = *reinterpret_cast<const uint32_t *>(a0);
+    uint32_t d1 = *reinterpret_cast<const uint32_t *>(a1);
+    uint32_t d2 = *reinterpret_cast<const uint32_t *>(a2);
+    uint32_t sh = (uint32_t)(p & 3);
+    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// VarInt::decode on a byte window.  `avail` = bytes left in the buffer at pos.
+// At most five bytes; the fifth byte's bits above 32 are dropped (checked_shl
+// only rejects a shift >= 32); a sixth byte is Overflow, unless the buffer ends
+// first (the byte is fetched before the shift is checked), then TryGet.
+__device__ __forceinline__ int varint32(uint64_t w, uint32_t avail, uint32_t &used, int32_t &out) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        if ((uint32_t)i >= avail) return NISSHI_TRY_GET;
+        uint32_t b = (uint32_t)(w >> (8 * i)) & 0xffu;
+        acc |= (b & 0x7fu) << (7 * i);
+        if (!(b & 0x80u)) {
+            used = i + 1;
+            out = (int32_t)(acc >> 1) ^ -(int32_t)(acc & 1u);
+            return NISSHI_OK;
+        }
+    }
+    return avail <= 5 ? NISSHI_TRY_GET : NISSHI_OVERFLOW;
+}
+
+struct Cursor {
+    const uint8_t *data;  // the batch's record_data
+    uint32_t len;
+    uint32_t pos;
+};
+
+__device__ __forceinline__ int read_varint(Cursor &c, int32_t &out) {
+    if (c.pos >= c.len) return NISSHI_TRY_GET;
+    uint32_t used = 0;
+    int st = varint32(window64(c.data, c.pos, c.len), c.len - c.pos, used, out);
+    c.pos += used;
+    return st;
+}
+
+// LongVarInt::decode: up to ten bytes, the eleventh overflows.
+__device__ inline int read_varlong(Cursor &c, int64_t &out) {
+    uint64_t acc = 0;
+    uint32_t avail = c.len - c.pos;
+    if (c.pos >= c.len) return NISSHI_TRY_GET;
+    uint64_t w = window64(c.data, c.pos, c.len);
+    for (int i = 0; i < 11; i++) {
+        if ((uint32_t)i >= avail) return NISSHI_TRY_GET;
+        if (i == 10) return NISSHI_OVERFLOW;
+        if (i == 8) w = window64(c.data, c.pos + 8, c.len);
+        uint32_t b = (uint32_t)(w >> (8 * (i & 7))) & 0xffu;
+        acc |= (uint64_t)(b & 0x7fu) << (7 * i);  // i == 9: only bit 63 survives
+        if (!(b & 0x80u)) {
+            c.pos += i + 1;
+            out = (int64_t)(acc >> 1) ^ -(int64_t)(acc & 1u);
+            return NISSHI_OK;
+        }
+    }
+    return NISSHI_OVERFLOW;
+}
+
+// Octets::decode: -1 is None; any other negative length, or one past the end,
+// panics in Bytes::split_to.
+__device__ __forceinline__ int read_octets(Cursor &c, uint32_t &off, int32_t &len) {
+    int st = read_varint(c, len);
+    if (st) return st;
+    off = c.pos;
+    if (len == -1) return NISSHI_OK;
+    if (len < 0 || (uint32_t)len > c.len - c.pos) return NISSHI_MALFORMED;
+    c.pos += (uint32_t)len;
+    return NISSHI_OK;
+}
+
+struct RecordFields {
+    int32_t length;
+    uint32_t attributes;
+    int64_t timestamp_delta;
+    int32_t offset_delta;
+    uint32_t key_off, val_off;
+    int32_t key_len, val_len;
+    int32_t hdr_count;
+    uint32_t hdr_pos;  // position of the first header, after the count
+};
+
+// Record::decode.  Walks the headers to find where the record ends; the header
+// spans themselves are extracted in a later pass once their slots are known.
+__device__ inline int read_record(Cursor &c, RecordFields &r) {
+    int st;
+    if ((st = read_varint(c, r.length))) return st;
+    if (c.pos >= c.len) return NISSHI_MALFORMED;  // get_u8 on an empty buffer panics
+    r.attributes = c.data[c.pos];
+    c.pos += 1;
+    if ((st = read_varlong(c, r.timestamp_delta))) return st;
+    if ((st = read_varint(c, r.offset_delta))) return st;
+    if ((st = read_octets(c, r.key_off, r.key_len))) return st;
+    if ((st = read_octets(c, r.val_off, r.val_len))) return st;
+    if ((st = read_varint(c, r.hdr_count))) return st;
+    if (r.hdr_count < 0) return NISSHI_MALFORMED;  // Vec::with_capacity(huge) panics
+    r.hdr_pos = c.pos;
+    for (int32_t i = 0; i < r.hdr_count; i++) {
+        uint32_t off;
+        int32_t len;
+        if ((st = read_octets(c, off, len))) return st;
+        if ((st = read_octets(c, off, len))) return st;
+    }
+    return NISSHI_OK;
+}
+
+__device__ __forceinline__ uint32_t be32(const uint8_t *p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+__device__ __forceinline__ uint64_t be64(const uint8_t *p) {
+    return ((uint64_t)be32(p) << 32) | be32(p + 4);
+}
+__device__ __forceinline__ uint16_t be16(const uint8_t *p) {
+    return (uint16_t)(((uint32_t)p[0] << 8) | p[1]);
+}
+
+}  // namespace nisshi

@@ -1,0 +1,256 @@
+"""ctypes binding of the C ABI in include/nisshi_hip.h (tansu_amd/lib/libnisshi_hip.so).
+
+PyTorch is used only for device memory and streams.  There is no CPU fallback:
+loading fails loudly when the HIP library has not been built, and creating a
+codec fails when no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import columns as C
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnisshi_hip.so")
+
+EXPORTS = [
+    "nisshi_hip_ctx_create", "nisshi_hip_ctx_destroy", "nisshi_hip_status_str",
+    "nisshi_hip_last_error", "nisshi_frame_split", "nisshi_records_prefix_decode",
+    "nisshi_records_prefix_encode", "nisshi_hip_count_dev", "nisshi_hip_decode_dev",
+    "nisshi_hip_encode_dev", "nisshi_hip_decode", "nisshi_hip_encode", "nisshi_hip_crc32c_dev",
+]
+
+
+class Totals(ctypes.Structure):
+    _fields_ = [("n_records", ctypes.c_uint64), ("n_headers", ctypes.c_uint64),
+                ("n_failed", ctypes.c_uint32), ("n_exact", ctypes.c_uint32),
+                ("out_bytes", ctypes.c_uint64)]
+
+
+class NisshiError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        name = C.STATUS_NAMES[status] if 0 <= status < len(C.STATUS_NAMES) else \
+            {8: "DEVICE_ERROR", 9: "INVALID_ARGUMENT"}.get(status, str(status))
+        super().__init__(f"nisshi_hip: {name} {detail}".strip())
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libnisshi_hip.so; raises if it is missing (build it with tansu_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -m tansu_amd.build` "
+                          "(there is no CPU fallback for the HIP codec)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    lib.nisshi_hip_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    lib.nisshi_hip_ctx_destroy.argtypes = [vp]
+    lib.nisshi_hip_ctx_destroy.restype = None
+    lib.nisshi_hip_status_str.argtypes = [i32]
+    lib.nisshi_hip_status_str.restype = ctypes.c_char_p
+    lib.nisshi_hip_last_error.argtypes = [vp]
+    lib.nisshi_hip_last_error.restype = ctypes.c_char_p
+    lib.nisshi_frame_split.argtypes = [vp, u64, vp, u64, ctypes.POINTER(u64)]
+    lib.nisshi_records_prefix_decode.argtypes = [vp, u64, i32, ctypes.POINTER(u64),
+                                                 ctypes.POINTER(u32), ctypes.POINTER(i32)]
+    lib.nisshi_records_prefix_encode.argtypes = [u32, i32, vp]
+    lib.nisshi_records_prefix_encode.restype = u64
+    lib.nisshi_hip_count_dev.argtypes = [vp, vp, u64, vp, u32, ctypes.POINTER(u64), vp]
+    lib.nisshi_hip_decode_dev.argtypes = [vp, vp, u64, vp, u32, i32, ctypes.POINTER(C.CColumns),
+                                          u64, u64, ctypes.POINTER(Totals), vp]
+    lib.nisshi_hip_encode_dev.argtypes = [vp, ctypes.POINTER(C.CColumns), u32, vp, vp, vp, u64, vp,
+                                          ctypes.POINTER(Totals), vp]
+    lib.nisshi_hip_decode.argtypes = [vp, vp, u64, vp, u32, i32, ctypes.POINTER(C.CColumns), u64,
+                                      u64, ctypes.POINTER(Totals)]
+    lib.nisshi_hip_encode.argtypes = [vp, ctypes.POINTER(C.CColumns), u32, u64, u64, vp, u64, vp,
+                                      vp, u64, vp, ctypes.POINTER(Totals)]
+    lib.nisshi_hip_crc32c_dev.argtypes = [vp, vp, u64, ctypes.POINTER(u32), vp]
+    _lib = lib
+    return lib
+
+
+def frame_split(blob: bytes) -> np.ndarray:
+    """Split a records blob into batches (host side).  Returns n + 1 offsets."""
+    lib = load()
+    cap = len(blob) // 12 + 2
+    off = np.zeros(cap, dtype=np.uint64)
+    n = ctypes.c_uint64(0)
+    buf = np.frombuffer(blob, dtype=np.uint8) if len(blob) else np.zeros(1, dtype=np.uint8)
+    st = lib.nisshi_frame_split(buf.ctypes.data, len(blob), off.ctypes.data, cap, ctypes.byref(n))
+    if st:
+        raise NisshiError(st)
+    return off[:n.value + 1].copy()
+
+
+_TORCH_BY_SIZE = None
+
+
+def _torch_dtype(np_dtype):
+    import torch
+    global _TORCH_BY_SIZE
+    if _TORCH_BY_SIZE is None:
+        _TORCH_BY_SIZE = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
+    return _TORCH_BY_SIZE[np.dtype(np_dtype).itemsize]
+
+
+class DeviceColumns:
+    """Columns resident in device memory (torch tensors, one per column)."""
+
+    def __init__(self, n_batches: int, rec_cap: int, hdr_cap: int, device):
+        import torch
+        self.n_batches, self.rec_cap, self.hdr_cap = n_batches, rec_cap, hdr_cap
+        self.t = {}
+        for group, n in ((C.BATCH_COLUMNS, n_batches), (C.RECORD_COLUMNS, rec_cap),
+                         (C.HEADER_COLUMNS, hdr_cap)):
+            for name, dt in group:
+                self.t[name] = torch.empty(max(n, 1), dtype=_torch_dtype(dt), device=device)
+        self.c = C.CColumns()
+        for name, _ in C.ALL_COLUMNS:
+            setattr(self.c, name, self.t[name].data_ptr())
+
+    @classmethod
+    def from_host(cls, cols: dict, device):
+        import torch
+        n_b = len(cols["status"])
+        n_r = len(cols["length"])
+        n_h = len(cols["hkey_off"])
+        self = cls(n_b, n_r, n_h, device)
+        for name, dt in C.ALL_COLUMNS:
+            src = np.ascontiguousarray(cols[name])
+            if len(src):
+                signed = src.view(np.dtype(f"i{src.dtype.itemsize}"))
+                self.t[name][:len(src)].copy_(torch.from_numpy(signed.copy()))
+        return self
+
+    def to_host(self, n_records: Optional[int] = None, n_headers: Optional[int] = None) -> dict:
+        n_records = self.rec_cap if n_records is None else n_records
+        n_headers = self.hdr_cap if n_headers is None else n_headers
+        out = {}
+        for group, n in ((C.BATCH_COLUMNS, self.n_batches), (C.RECORD_COLUMNS, n_records),
+                         (C.HEADER_COLUMNS, n_headers)):
+            for name, dt in group:
+                out[name] = self.t[name][:n].cpu().numpy().view(dt).copy()
+        return out
+
+
+class Codec:
+    """One context on one GPU.  Not thread safe: use one per thread."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the HIP codec has no CPU fallback")
+        self.lib = load()
+        self.device = torch.device("cuda", device)
+        ctx = ctypes.c_void_p()
+        st = self.lib.nisshi_hip_ctx_create(device, ctypes.byref(ctx))
+        if st:
+            raise NisshiError(st, "ctx_create")
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.nisshi_hip_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st:
+            raise NisshiError(st, (self.lib.nisshi_hip_last_error(self.ctx) or b"").decode())
+
+    def _stream(self):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- device-resident path -------------------------------------------------
+    def to_device(self, blob, batch_off):
+        """Copy a host blob and its n + 1 batch offsets to the GPU."""
+        import torch
+        arr = np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+        d_blob = torch.empty(len(arr) + 16, dtype=torch.uint8, device=self.device)
+        if len(arr):
+            d_blob[:len(arr)].copy_(torch.from_numpy(arr.copy()))
+        off = np.ascontiguousarray(batch_off, dtype=np.uint64).view(np.int64)
+        d_off = torch.from_numpy(off.copy()).to(self.device)
+        return d_blob, d_off
+
+    def count_dev(self, d_blob, blob_len: int, d_off, n_batches: int) -> int:
+        n = ctypes.c_uint64(0)
+        self._check(self.lib.nisshi_hip_count_dev(self.ctx, d_blob.data_ptr(), blob_len,
+                                                  d_off.data_ptr(), n_batches, ctypes.byref(n),
+                                                  self._stream()))
+        return n.value
+
+    def decode_dev(self, d_blob, blob_len: int, d_off, n_batches: int, cols: DeviceColumns,
+                   by_value: bool = True, sync: bool = True) -> Optional[Totals]:
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_decode_dev(
+            self.ctx, d_blob.data_ptr(), blob_len, d_off.data_ptr(), n_batches, int(by_value),
+            ctypes.byref(cols.c), cols.rec_cap, cols.hdr_cap,
+            ctypes.byref(totals) if sync else None, self._stream()))
+        return totals if sync else None
+
+    def encode_dev(self, cols: DeviceColumns, n_batches: int, d_src, d_src_off, d_out, out_cap: int,
+                   d_out_off, sync: bool = True) -> Optional[Totals]:
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_encode_dev(
+            self.ctx, ctypes.byref(cols.c), n_batches, d_src.data_ptr(), d_src_off.data_ptr(),
+            d_out.data_ptr(), out_cap, d_out_off.data_ptr(),
+            ctypes.byref(totals) if sync else None, self._stream()))
+        return totals if sync else None
+
+    def crc32c_dev(self, d_data, length: int, offset: int = 0) -> int:
+        out = ctypes.c_uint32(0)
+        self._check(self.lib.nisshi_hip_crc32c_dev(self.ctx, d_data.data_ptr() + offset, length,
+                                                   ctypes.byref(out), self._stream()))
+        return out.value
+
+    # ---- host-buffer path -----------------------------------------------------
+    def decode(self, blob: bytes, batch_off, by_value: bool = True, rec_cap: Optional[int] = None,
+               hdr_cap: Optional[int] = None):
+        """Decode host bytes; returns (cols: dict of numpy arrays, totals)."""
+        arr = np.frombuffer(bytes(blob), dtype=np.uint8)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+        n_b = len(off) - 1
+        rec_cap = len(arr) // 7 + 1 if rec_cap is None else rec_cap
+        hdr_cap = len(arr) // 2 + 1 if hdr_cap is None else hdr_cap
+        cols = C.alloc_host(n_b, rec_cap, hdr_cap)
+        cc = C.as_c(cols)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_decode(
+            self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data, n_b,
+            int(by_value), ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(totals)))
+        return C.trim(cols, n_b, min(totals.n_records, rec_cap), min(totals.n_headers, hdr_cap)), totals
+
+    def encode(self, cols: dict, src: bytes, src_data_off, out_cap: Optional[int] = None):
+        """Encode host columns; returns (bytes, out_off np.uint64[n + 1], totals)."""
+        n_b = len(cols["status"])
+        sarr = np.frombuffer(bytes(src), dtype=np.uint8)
+        soff = np.ascontiguousarray(src_data_off, dtype=np.uint64)
+        if out_cap is None:
+            out_cap = 2 * len(sarr) + 128 * n_b + 64 * len(cols["length"]) + 1024
+        out = np.zeros(out_cap, dtype=np.uint8)
+        out_off = np.zeros(n_b + 1, dtype=np.uint64)
+        full = {k: np.ascontiguousarray(v) for k, v in cols.items()}
+        full = {k: (v if len(v) else np.zeros(1, dtype=v.dtype)) for k, v in full.items()}
+        cc = C.as_c(full)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_encode(
+            self.ctx, ctypes.byref(cc), n_b, len(cols["length"]), len(cols["hkey_off"]),
+            sarr.ctypes.data if len(sarr) else None, len(sarr),
+            soff.ctypes.data if len(soff) else None, out.ctypes.data, out_cap,
+            out_off.ctypes.data, ctypes.byref(totals)))
+        return out[:totals.out_bytes].tobytes(), out_off, totals
