@@ -110,8 +110,8 @@ __device__ __forceinline__ uint32_t fsh(uint32_t hi, uint32_t lo, int r) {
 // all come from lane 0's first two words and land in lane 63's last two.
 __device__ __forceinline__ void crc_fold_row(uint32_t (&a)[4], const uint32_t (&nx)[4],
                                              int lane) {
-    uint64_t low = ((uint64_t)__builtin_amdgcn_readfirstlane(a[1]) << 32) |
-                   __builtin_amdgcn_readfirstlane(a[0]);
+    uint64_t low = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(a[1]) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane(a[0]);
     uint64_t wrap = (low << 2) ^ (low << 5) ^ (low << 16) ^ (low << 21) ^ (low << 32) ^
                     (low << 37) ^ (low << 43) ^ (low << 59);  // 64 - t for every t > 0
     uint32_t top = lane == 63 ? 0xFFFFFFFFu : 0u;
