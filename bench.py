@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Device-resident RecordBatch v2 decode throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2]
+
+One step = one decode of the whole resident workload (batch headers, CRC-32C,
+record walk into columns, header spans) through the C ABI.  At N > 1 every rank
+decodes its own shard of topic-partitions (weak scaling, no collective on the
+data path); the only communication is the barrier around the timed region and
+the max-reduce of the elapsed time.
+
+Prints one JSON line on rank 0.  `roofline` is for the kernel that takes most of
+a step, with its duration measured by HIP events on the launch stream during the
+timed steps.  `cpu_baseline` times the CPU restatement in oracle/ (a port of the
+reference's algorithm, one core) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+# Which input bytes and which columns each decode kernel is responsible for, as
+# a fraction of the algorithmic bytes of a decode:
+#   in_bytes + 64 * n_batches + 41 * n_records + 16 * n_headers
+KERNEL_BYTES = {
+    "crc_chunks_kernel": lambda s: s["in_bytes"],
+    "walk_kernel": lambda s: s["in_bytes"] + 41 * s["n_records"],
+    "headers_kernel": lambda s: 16 * s["n_headers"],
+    "batch_header_kernel": lambda s: 64 * s["n_batches"],
+    "decode_fused_kernel": lambda s: s["in_bytes"] + 41 * s["n_records"] + 64 * s["n_batches"],
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-copies", action="store_true",
+                    help="also time the host-buffer entry point (PCIe inclusive), to stderr")
+    args = ap.parse_args()
+
+    import torch
+    from tansu_amd import columns as C, hip, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    codec = hip.Codec(local)
+
+    # ---- this rank's shard: its own topic-partitions, same shape, own seed
+    shape, counts, seed = synth.config(args.workload, args.scale)
+    blob, off, n_records, n_headers = synth.make_batches(shape, counts, seed + 7919 * rank)
+    n_batches = len(counts)
+    in_bytes = len(blob)
+    d_blob, d_off = codec.to_device(blob, off)
+    cols = hip.DeviceColumns(n_batches, n_records, max(n_headers, 1), dev)
+    # fill the CRC fields from the codec's own CRC (checked against the CPU
+    # restatement in tests/ and in smoke()), so the decode sees valid batches
+    codec.decode_dev(d_blob, in_bytes, d_off, n_batches, cols)
+    crc = cols.t["crc_computed"][:n_batches].clone()
+    starts = d_off[:n_batches] + 17
+    for k in range(4):
+        d_blob[starts + k] = ((crc >> (8 * (3 - k))) & 0xFF).to(torch.uint8)
+    totals = codec.decode_dev(d_blob, in_bytes, d_off, n_batches, cols)
+    assert (totals.n_records, totals.n_headers, totals.n_failed) == (n_records, n_headers, 0), \
+        (totals.n_records, totals.n_headers, totals.n_failed)
+    assert bool((cols.t["crc"][:n_batches] == cols.t["crc_computed"][:n_batches]).all())
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        codec.decode_dev(d_blob, in_bytes, d_off, n_batches, cols, sync=False)
+    barrier()
+    codec.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codec.decode_dev(d_blob, in_bytes, d_off, n_batches, cols, sync=False)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    kt = codec.kernel_times()
+    codec.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    stats = dict(in_bytes=in_bytes, n_batches=n_batches, n_records=n_records, n_headers=n_headers)
+    step_ms = elapsed / args.steps * 1e3
+    total_records = n_records * world
+    algo_bytes = C.algorithmic_decode_bytes(n_batches, n_records, n_headers, in_bytes)
+    name, (ms, launches) = max(kt.items(), key=lambda kv: kv[1][0])
+    avg_ms = ms / launches
+    k_bytes = KERNEL_BYTES.get(name, lambda s: 0)(stats)
+    achieved = k_bytes / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = tj.get(args.workload, {}).get(name)
+    result = {
+        "metric": "device-resident RecordBatch v2 decode",
+        "value": total_records * args.steps / elapsed,
+        "unit": "records/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": step_ms,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": {"c1": "C1: 10k batches x 100 records x 100 B values",
+                         "c2": "C2: small records, 16 B keys, 64 B values, 2 headers, 1k records/batch",
+                         "c3": "C3: large values, 1 MiB values, 4 records/batch",
+                         "c5": "C5: ragged batches, 1-10k records of 100 B"}[args.workload],
+            "batches_per_gpu": n_batches,
+            "records_per_gpu": n_records,
+            "input_bytes_per_gpu": in_bytes,
+            "sharding": f"{world} x independent partitions, no collective",
+        },
+        "input_gbs": in_bytes * world * args.steps / elapsed / 1e9,
+        "algorithmic_gbs": algo_bytes * world * args.steps / elapsed / 1e9,
+        "roofline": {
+            "bound": "hbm",
+            "kernel": name,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel_ms": avg_ms,
+            "kernel_algorithmic_bytes": k_bytes,
+        },
+        "kernels_ms": {k: v[0] / v[1] for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
+    }
+
+    if args.with_copies:
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            codec.decode(blob, off, rec_cap=n_records, hdr_cap=max(n_headers, 1))
+        dt = (time.perf_counter() - t0) / reps
+        print(f"[with-copies] host-buffer decode (H2D blob + kernels + D2H columns): "
+              f"{n_records / dt / 1e6:.1f} M records/s, {in_bytes / dt / 1e9:.2f} GB/s of input",
+              file=sys.stderr)
+
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(blob, off, n_batches, n_records)
+
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(blob, off, n_batches, n_records):
+    """The CPU restatement (oracle/, a port of the reference's algorithm) decoding
+    a bounded sample of the same workload on one host core."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    probe = max(1, min(n_batches, 8))
+    t0 = time.perf_counter()
+    oracle.decode_columns(blob[:int(off[probe])], off[:probe + 1])
+    dt = max(time.perf_counter() - t0, 1e-6)
+    per_batch = dt / probe
+    sample = int(max(probe, min(n_batches, 12.0 / per_batch)))
+    sub = blob[:int(off[sample])]
+    t0 = time.perf_counter()
+    st, cols, nr, nh = oracle.decode_columns(sub, off[:sample + 1])
+    dt = time.perf_counter() - t0
+    assert st == 0 and (cols["status"] == 0).all()
+    return {
+        "value": nr / dt,
+        "unit": "records/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {sample} of {n_batches} batches ({nr} records, {len(sub)} bytes) in {dt:.2f} s; "
+                  "C restatement of nisshi-sans-io (oracle/), heap Vec<Record>-style decode then columns",
+        "input_gbs": len(sub) / dt / 1e9,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "gf2_crc32c.h"
 #include "nisshi_hip.h"

@@ -21,6 +21,7 @@ EXPORTS = [
     "nisshi_hip_last_error", "nisshi_frame_split", "nisshi_records_prefix_decode",
     "nisshi_records_prefix_encode", "nisshi_hip_count_dev", "nisshi_hip_decode_dev",
     "nisshi_hip_encode_dev", "nisshi_hip_decode", "nisshi_hip_encode", "nisshi_hip_crc32c_dev",
+    "nisshi_hip_profile_enable", "nisshi_hip_profile_get", "nisshi_hip_profile_name",
 ]
 
 
@@ -73,6 +74,10 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_encode.argtypes = [vp, ctypes.POINTER(C.CColumns), u32, u64, u64, vp, u64, vp,
                                       vp, u64, vp, ctypes.POINTER(Totals)]
     lib.nisshi_hip_crc32c_dev.argtypes = [vp, vp, u64, ctypes.POINTER(u32), vp]
+    lib.nisshi_hip_profile_enable.argtypes = [vp, i32]
+    lib.nisshi_hip_profile_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
+    lib.nisshi_hip_profile_name.argtypes = [i32]
+    lib.nisshi_hip_profile_name.restype = ctypes.c_char_p
     _lib = lib
     return lib
 
@@ -174,6 +179,25 @@ class Codec:
     def _stream(self):
         import torch
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- per-kernel timing ----------------------------------------------------
+    def profile(self, on: bool):
+        self._check(self.lib.nisshi_hip_profile_enable(self.ctx, int(on)))
+
+    def kernel_times(self) -> dict:
+        """{kernel name: (total ms, launches)} since profile(True); waits for the events."""
+        out = {}
+        k = 0
+        while True:
+            name = self.lib.nisshi_hip_profile_name(k)
+            if name is None:
+                break
+            ms, n = ctypes.c_double(0), ctypes.c_uint64(0)
+            self._check(self.lib.nisshi_hip_profile_get(self.ctx, k, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                out[name.decode()] = (ms.value, n.value)
+            k += 1
+        return out
 
     # ---- device-resident path -------------------------------------------------
     def to_device(self, blob, batch_off):
