@@ -71,7 +71,7 @@ typedef struct nisshi_columns {
     uint64_t *data_off;     /* offset of record_data in the blob */
     uint32_t *data_len;
     uint32_t *rec_base;  /* index of the batch's first record in the record columns */
-    uint32_t *hdr_base;  /* index of the batch's first header in the header columns */
+    uint32_t *hdr_base;  /* slot of the batch's first header (its headers need not be one run) */
     uint32_t *hdr_count; /* headers in the batch */
     int32_t *status;
     /* per record (record.rs:172-198) */
@@ -83,7 +83,7 @@ typedef struct nisshi_columns {
     int32_t *key_len;
     uint32_t *val_off;
     int32_t *val_len;
-    uint32_t *rhdr_base; /* index of the record's first header in the header columns */
+    uint32_t *rhdr_base; /* slot of the record's first header; a record's headers are contiguous */
     int32_t *rhdr_count;
     /* per header (header.rs:21-29) */
     uint32_t *hkey_off;
@@ -94,7 +94,7 @@ typedef struct nisshi_columns {
 
 typedef struct nisshi_totals {
     uint64_t n_records;  /* record slots used (a failed batch may leave its slots unused) */
-    uint64_t n_headers;  /* header slots used */
+    uint64_t n_headers;  /* header slots handed out: at least the number of headers (see below) */
     uint32_t n_failed;   /* batches whose status is not NISSHI_OK */
     uint32_t n_exact;    /* batches that needed the sequential walk (length disagreed with the fields) */
     uint64_t out_bytes;  /* encode: bytes written */
@@ -132,7 +132,14 @@ int nisshi_hip_count_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t bl
  * deflated::Batch) does; 0 keeps attributes verbatim (the by-reference
  * conversion).  With totals == NULL the call only enqueues work; otherwise it
  * waits for the stream and fills *totals.  A batch that fails leaves its
- * status and no valid records; the call still returns NISSHI_OK. */
+ * status and no valid records; the call still returns NISSHI_OK.
+ *
+ * Header slots are handed out in runs from one cursor while batches decode in
+ * parallel: a record's headers are contiguous from rhdr_base, but the order of
+ * runs between batches is not defined and a batch may leave up to 4096 slots of
+ * its last run unused, so size hdr_cap with that slack (a batch whose headers
+ * do not fit gets NISSHI_CAPACITY).  Batches whose records all carry the same
+ * number of headers use exactly their header count. */
 int nisshi_hip_decode_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
                           const uint64_t *d_batch_off, uint32_t n_batches, int by_value,
                           const nisshi_columns *d_cols, uint64_t rec_cap, uint64_t hdr_cap,

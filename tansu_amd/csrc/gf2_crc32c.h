@@ -195,6 +195,92 @@ __device__ inline uint32_t crc_rows(const uint8_t *base, uint64_t grid, uint64_t
     return crc_row_residue(acc, lane, t);
 }
 
+
+// Incremental form of crc_rows for a wave that interleaves the CRC with other
+// work on the same bytes: rows are consumed in order, a few loads in flight at a
+// time, so that what the wave parses next has just been fetched.
+struct CrcStream {
+    const uint8_t *base;
+    uint64_t grid, lo, hi;
+    uint32_t rows, next_row;
+    uint32_t acc[4];
+    int lane;
+
+    __device__ __forceinline__ void init(const uint8_t *base_, uint64_t lo_, uint64_t hi_, int lane_) {
+        base = base_;
+        lo = lo_;
+        hi = hi_;
+        grid = lo_ & ~uint64_t(15);
+        rows = (uint32_t)((hi_ - grid + kRowBytes - 1) / kRowBytes);
+        next_row = 0;
+        lane = lane_;
+        acc[0] = acc[1] = acc[2] = acc[3] = 0;
+    }
+
+    // first row index that does not touch absolute offset < `addr`
+    __device__ __forceinline__ uint32_t row_after(uint64_t addr) const {
+        if (addr <= grid) return 0;
+        uint64_t r = (addr - grid + kRowBytes - 1) / kRowBytes;
+        return r < rows ? (uint32_t)r : rows;
+    }
+
+    __device__ __forceinline__ void load(uint32_t r, uint32_t (&nx)[4]) const {
+        uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
+        nx[0] = nx[1] = nx[2] = nx[3] = 0;
+        if (addr + 16 > lo && addr < hi) {
+            uint4 v = *reinterpret_cast<const uint4 *>(base + addr);
+            nx[0] = v.x;
+            nx[1] = v.y;
+            nx[2] = v.z;
+            nx[3] = v.w;
+            if (addr < lo || addr + 16 > hi) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) nx[i] &= byte_mask(addr + 4 * i, lo, hi);
+            }
+        }
+        if (addr + 16 > lo && addr < lo + 4) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) nx[i] ^= byte_mask(addr + 4 * i, lo, lo + 4);
+        }
+    }
+
+    __device__ __forceinline__ void take(const uint32_t (&nx)[4], uint32_t r) {
+        if (r == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = nx[i];
+        } else {
+            crc_fold_row(acc, nx, lane);
+        }
+    }
+
+    // consume rows up to (not including) `target`
+    __device__ inline void advance(uint32_t target) {
+        if (target > rows) target = rows;
+        while (next_row < target) {
+            uint32_t nb = target - next_row;
+            uint32_t n0[4], n1[4], n2[4], n3[4];
+            load(next_row, n0);
+            if (nb > 1) load(next_row + 1, n1);
+            if (nb > 2) load(next_row + 2, n2);
+            if (nb > 3) load(next_row + 3, n3);
+            take(n0, next_row);
+            if (nb > 1) take(n1, next_row + 1);
+            if (nb > 2) take(n2, next_row + 2);
+            if (nb > 3) take(n3, next_row + 3);
+            next_row += nb < 4 ? nb : 4;
+        }
+    }
+
+    // the CRC-32C of [lo, hi)
+    __device__ inline uint32_t finish(const CrcTables *t) {
+        advance(rows);
+        if (hi == lo) return 0;
+        uint32_t r = crc_row_residue(acc, lane, t);
+        uint64_t pad = grid + (uint64_t)rows * kRowBytes - hi;
+        return ~gf_mulmod(r, t->inv8[pad]);
+    }
+};
+
 #endif  // __HIPCC__
 
 }  // namespace nisshi

@@ -5,12 +5,12 @@
 // Decode pipeline (all on one stream):
 //   batch_header_kernel   one lane per batch: the 61-byte header, its checks, the record_data span
 //   scan_batches_kernel   exclusive scans over batches: record slots, CRC work items
-//   crc_chunks_kernel     one wave per 64 KiB of batch: CRC-32C by sparse folding
-//   crc_finish_kernel     combines the chunks of batches larger than one chunk
-//   walk_kernel           one wave per batch: hop over the length varints, then one lane per record
+//   crc_chunks_kernel     large batches only: one wave per 64 KiB, CRC-32C by sparse folding
+//   crc_finish_kernel     combines the chunks of those batches
+//   decode_fused_kernel   one wave per batch: CRC-32C streamed just ahead of the record walk;
+//                         record starts by speculation, one lane per record, header spans inline
 //   exact_kernel          sequential field walk for batches whose lengths disagree with their fields
-//   scan_headers_kernel   exclusive scan of header counts over batches
-//   headers_kernel        one wave per batch: header spans into their slots
+//   finish_kernel         totals
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -180,35 +180,12 @@ __global__ void scan_batches_kernel(uint32_t n, nisshi_columns c, Work w) {
     }
 }
 
-__global__ void scan_headers_kernel(uint32_t n, nisshi_columns c, Work w) {
-    __shared__ uint32_t lds[16];
-    uint32_t run = 0, failed = 0, exact = 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x) {
-        uint32_t b = base + threadIdx.x;
-        bool ok = b < n && c.status[b] == NISSHI_OK;
-        uint32_t cnt = ok ? c.hdr_count[b] : 0;
-        uint32_t tot;
-        uint32_t e = block_exclusive_scan(cnt, lds, tot);
-        if (b < n) c.hdr_base[b] = run + e;
-        run += tot;
-        block_exclusive_scan(b < n && !ok ? 1u : 0u, lds, tot);
-        failed += tot;
-        block_exclusive_scan(b < n && (w.flags[b] & kFlagExact) ? 1u : 0u, lds, tot);
-        exact += tot;
-    }
-    if (threadIdx.x == 0) {
-        w.totals[1] = run;
-        w.totals[2] = failed;
-        w.totals[3] = exact;
-    }
-}
-
 // ------------------------------------------------------------ CRC-32C
 
 // One wave per work item: item -> (batch, chunk) by binary search in the scan.
 __global__ void crc_chunks_kernel(const uint8_t *blob, const uint64_t *batch_off,
                                   const int32_t *batch_length, uint32_t n, uint32_t *crc_out,
-                                  Work w, const CrcTables *t) {
+                                  Work w, const CrcTables *t, uint32_t min_chunks) {
     uint32_t item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     uint32_t total = w.chunk_base[n];
@@ -221,6 +198,7 @@ __global__ void crc_chunks_kernel(const uint8_t *blob, const uint64_t *batch_off
     uint32_t b = lo_b;
     uint32_t chunk = item - w.chunk_base[b];
     uint32_t chunks = w.n_chunks[b];
+    if (chunks < min_chunks) return;  // small batches get their CRC from the fused walk
     uint64_t lo = batch_off[b] + 21;
     uint64_t hi = lo + (uint64_t)batch_length[b] - 9;
     uint64_t grid = lo & ~uint64_t(15);
@@ -243,11 +221,12 @@ __global__ void crc_chunks_kernel(const uint8_t *blob, const uint64_t *batch_off
 
 // Batches of more than one chunk: R = sum over chunks of R_c * x^(8 * bytes after chunk c).
 __global__ void crc_finish_kernel(const uint64_t *batch_off, const int32_t *batch_length,
-                                  uint32_t n, uint32_t *crc_out, Work w, const CrcTables *t) {
+                                  uint32_t n, uint32_t *crc_out, Work w, const CrcTables *t,
+                                  uint32_t min_chunks) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
     uint32_t chunks = w.n_chunks[b];
-    if (chunks < 2) return;
+    if (chunks < 2 || chunks < min_chunks) return;
     uint64_t lo = batch_off[b] + 21;
     uint64_t hi = lo + (uint64_t)batch_length[b] - 9;
     uint64_t grid = lo & ~uint64_t(15);
@@ -262,7 +241,7 @@ __global__ void crc_finish_kernel(const uint64_t *batch_off, const int32_t *batc
 // ------------------------------------------------------------ record walk
 
 __device__ __forceinline__ void store_record(const nisshi_columns &c, uint32_t r,
-                                             const RecordFields &f, uint32_t hdr_rel) {
+                                             const RecordFields &f, uint32_t hdr_slot) {
     c.length[r] = f.length;
     c.rattributes[r] = (uint8_t)f.attributes;
     c.timestamp_delta[r] = f.timestamp_delta;
@@ -271,68 +250,172 @@ __device__ __forceinline__ void store_record(const nisshi_columns &c, uint32_t r
     c.key_len[r] = f.key_len;
     c.val_off[r] = f.val_off;
     c.val_len[r] = f.val_len;
-    c.rhdr_base[r] = hdr_rel;  // relative to the batch until headers_kernel adds hdr_base
+    c.rhdr_base[r] = hdr_slot;
     c.rhdr_count[r] = f.hdr_count;
 }
 
-// One wave per batch.  Phase 1 hops over the length varints to find up to 64
-// record starts; phase 2 gives each start to a lane, which decodes the fields
-// and checks that they end where the length said.  The reference never uses the
-// length to delimit a record (record.rs:259-265), so any disagreement, and any
-// decode error, hands the batch to exact_kernel, which walks field by field.
-__global__ void walk_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, Work w,
-                            uint64_t rec_cap) {
-    uint32_t b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (b >= n) return;
-    if (c.status[b] != NISSHI_OK || (w.flags[b] & kFlagExact)) return;
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Header slots are handed out from one cursor in runs, so that a batch's
+// headers sit in a few contiguous pieces and a record's headers are always
+// contiguous; the order of the pieces between batches is not defined.
+constexpr uint32_t kHdrRunMax = 4096;
+
+// The record walk of one batch by one wave.  Returns false when the batch has to
+// be walked sequentially (exact_kernel): a length that disagrees with the fields
+// it describes, or any decode error.
+//
+// Record starts are found 64 at a time by speculation: lane i assumes that the
+// i-th next record starts i * S bytes on, S being the size of the record before,
+// and decodes the length varint there.  Lanes up to and including the first one
+// whose size differs from S did start on a record, and the walk resumes after
+// that lane's record.  Batches of equal-sized records resolve 64 records per
+// step, ragged ones at least one.  Each resolved record is then decoded by its
+// lane and must end where its length said.
+__device__ inline bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
+                                  const Work &w, uint64_t hdr_cap, CrcStream *crc, int lane) {
     uint32_t count = c.record_count[b];
     uint32_t rbase = c.rec_base[b];
-    if ((uint64_t)rbase + count > rec_cap) {
-        if (lane == 0) c.status[b] = NISSHI_CAPACITY;
-        return;
-    }
-    Cursor hop{blob + c.data_off[b], c.data_len[b], 0};
-    uint32_t hdr_run = 0;
-    for (uint32_t k = 0; k < count; k += kWave) {
+    uint64_t data_off = c.data_off[b];
+    Reader rd(blob + data_off, c.data_len[b]);
+    unsigned long long *hdr_cursor = reinterpret_cast<unsigned long long *>(w.totals + 1);
+    uint64_t run_pos = 0, run_end = 0;  // header slots in hand
+    uint32_t hdr_total = 0, first_slot = 0;
+    uint32_t pos = 0;
+    uint32_t S = count ? rd.len / count : 0;
+    for (uint32_t k = 0; k < count;) {
         uint32_t m = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
-        uint32_t my_start = 0, my_end = 0;
-        bool bad = false;
-        for (uint32_t i = 0; i < m; i++) {
-            uint32_t start = hop.pos;
-            int32_t len;
-            int st = read_varint(hop, len);
-            if (st != NISSHI_OK || len < 0 || (uint32_t)len > hop.len - hop.pos) {
-                bad = true;
-                break;
+        uint32_t found = 0, my_start = 0, my_size = 0;
+        while (found < m) {
+            if (crc) crc->advance(crc->row_after(data_off + pos + (uint64_t)(m - found) * S + 64));
+            uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
+            uint32_t guess = guess64 < rd.len ? (uint32_t)guess64 : rd.len;
+            uint32_t p = guess;
+            int32_t len = 0;
+            int st = rd.varint(p, len);
+            bool ok = st == NISSHI_OK && len >= 0 && (uint32_t)len <= rd.len - p;
+            uint32_t size = ok ? p - guess + (uint32_t)len : 0;
+            uint64_t okmask = __ballot(ok);
+            if (!(okmask & 1)) return false;
+            uint64_t same = __ballot(ok && size == S);
+            uint32_t good = ~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64;
+            uint32_t v = good;  // lanes below `good` are records of size S
+            if (good < 64 && ((okmask >> good) & 1)) v = good + 1;
+            if (v > m - found) v = m - found;
+            int src = lane - (int)found;
+            uint32_t s_start = __shfl(guess, src & 63, 64);
+            uint32_t s_size = __shfl(size, src & 63, 64);
+            if (src >= 0 && (uint32_t)src < v) {
+                my_start = s_start;
+                my_size = s_size;
             }
-            hop.pos += (uint32_t)len;
-            if ((uint32_t)lane == i) {
-                my_start = start;
-                my_end = hop.pos;
-            }
+            S = __shfl(size, (int)v - 1, 64);
+            pos = __shfl(guess, (int)v - 1, 64) + S;
+            found += v;
         }
+        // ---- one lane per record
         RecordFields f;
-        if (!bad && (uint32_t)lane < m) {
-            Cursor cur{hop.data, hop.len, my_start};
-            int st = read_record(cur, f);
-            bad = st != NISSHI_OK || cur.pos != my_end;
+        bool live = (uint32_t)lane < m;
+        bool bad = false;
+        uint32_t p = my_start;
+        if (live) bad = read_record_head(rd, p, f) != NISSHI_OK;
+        uint32_t hc = live && !bad ? (uint32_t)f.hdr_count : 0;
+        uint32_t inc = wave_inclusive_scan(hc, lane);
+        uint32_t total = __shfl(inc, 63, 64);
+        uint64_t slot = 0;
+        if (total) {
+            // records whose headers fit in the run in hand use it, the rest a new run
+            uint64_t room = run_end - run_pos;
+            bool fits = inc <= room;
+            uint64_t fit_mask = __ballot(fits);
+            uint32_t n_fit = fit_mask == ~0ull ? 64 : (uint32_t)__ffsll((long long)~fit_mask) - 1;
+            uint32_t used_old = n_fit ? __shfl(inc, (int)n_fit - 1, 64) : 0;
+            uint32_t rest = total - used_old;
+            uint64_t new_base = 0;
+            uint32_t grab = 0;
+            if (rest) {
+                // take enough for the records still to come at this round's density
+                uint64_t ahead = (uint64_t)total * (count - k - m) / m;
+                grab = rest + (uint32_t)(ahead < kHdrRunMax ? ahead : kHdrRunMax);
+                if (lane == 0) new_base = atomicAdd(hdr_cursor, (unsigned long long)grab);
+                new_base = __shfl(new_base, 0, 64);
+                if (new_base + grab > hdr_cap) {
+                    if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+                    return true;
+                }
+            }
+            slot = fits ? run_pos + (inc - hc) : new_base + (inc - hc - used_old);
+            if (rest) {
+                run_pos = new_base + rest;
+                run_end = new_base + grab;
+            } else {
+                run_pos += total;
+            }
+            if (hdr_total == 0) first_slot = (uint32_t)__shfl(slot, __ffsll((long long)__ballot(hc > 0)) - 1, 64);
+            hdr_total += total;
         }
-        if (__any(bad)) {
-            if (lane == 0) w.flags[b] |= kFlagExact;
-            return;
+        for (uint32_t j = 0; j < hc && !bad; j++) {
+            uint32_t ko, vo;
+            int32_t kl, vl;
+            bad = rd.octets(p, ko, kl) != NISSHI_OK || rd.octets(p, vo, vl) != NISSHI_OK;
+            if (!bad) {
+                c.hkey_off[slot + j] = ko;
+                c.hkey_len[slot + j] = kl;
+                c.hval_off[slot + j] = vo;
+                c.hval_len[slot + j] = vl;
+            }
         }
-        uint32_t hc = (uint32_t)lane < m ? (uint32_t)f.hdr_count : 0;
-        uint32_t inc = hc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        if ((uint32_t)lane < m) store_record(c, rbase + k + lane, f, hdr_run + inc - hc);
-        hdr_run += __shfl(inc, 63, 64);
+        if (live && !bad) bad = p != my_start + my_size;
+        if (__any(bad)) return false;
+        if (live) store_record(c, rbase + k + lane, f, (uint32_t)slot);
+        k += m;
     }
-    if (lane == 0) c.hdr_count[b] = hdr_run;
+    if (lane == 0) {
+        c.hdr_count[b] = hdr_total;
+        c.hdr_base[b] = first_slot;
+    }
+    return true;
+}
+
+// One wave per batch: CRC-32C of the batch streamed just ahead of the record
+// walk, so the bytes the walk gathers have just come through the cache, and the
+// batch is read from HBM once.  Batches of kBigChunks chunks or more get their
+// CRC from crc_chunks_kernel instead (one wave cannot stream them fast enough).
+constexpr uint32_t kBigChunks = 8;
+
+__global__ __launch_bounds__(64) void decode_fused_kernel(const uint8_t *blob,
+                                                          const uint64_t *batch_off, uint32_t n,
+                                                          nisshi_columns c, Work w, uint64_t rec_cap,
+                                                          uint64_t hdr_cap, const CrcTables *t) {
+    uint32_t b = blockIdx.x;
+    int lane = threadIdx.x;
+    if (b >= n) return;
+    uint32_t chunks = w.n_chunks[b];
+    bool do_crc = chunks >= 1 && chunks < kBigChunks;
+    bool do_walk = c.status[b] == NISSHI_OK && !(w.flags[b] & kFlagExact);
+    if (do_walk && (uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
+        if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+        do_walk = false;
+    }
+    CrcStream crc;
+    if (do_crc) {
+        uint64_t lo = batch_off[b] + 21;
+        crc.init(blob, lo, lo + (uint64_t)c.batch_length[b] - 9, lane);
+    }
+    if (do_walk && !walk_batch(blob, b, c, w, hdr_cap, do_crc ? &crc : nullptr, lane)) {
+        if (lane == 0) w.flags[b] |= kFlagExact;
+    }
+    if (do_crc) {
+        uint32_t v = crc.finish(t);
+        if (lane == 0) c.crc_computed[b] = v;
+    }
 }
 
 // One lane per flagged batch: Record::decode in sequence, exactly as
@@ -340,7 +423,7 @@ __global__ void walk_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, W
 // error ends the batch with its status; records are stored only while the batch
 // has slots (a batch whose count cannot fit has none and only gets its status).
 __global__ void exact_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, Work w,
-                             uint64_t rec_cap) {
+                             uint64_t rec_cap, uint64_t hdr_cap) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
     if (!(w.flags[b] & kFlagExact) || c.status[b] != NISSHI_OK) return;
@@ -351,56 +434,60 @@ __global__ void exact_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, 
         c.status[b] = NISSHI_CAPACITY;
         return;
     }
-    Cursor cur{blob + c.data_off[b], c.data_len[b], 0};
-    uint32_t hdr_run = 0;
+    unsigned long long *hdr_cursor = reinterpret_cast<unsigned long long *>(w.totals + 1);
+    Reader rd(blob + c.data_off[b], c.data_len[b]);
+    uint32_t pos = 0, hdr_total = 0, first_slot = 0;
     int st = NISSHI_OK;
-    for (uint32_t k = 0; k < count; k++) {
+    for (uint32_t k = 0; k < count && st == NISSHI_OK; k++) {
         RecordFields f;
-        st = read_record(cur, f);
+        st = read_record_head(rd, pos, f);
         if (st) break;
-        if (k < slots) store_record(c, rbase + k, f, hdr_run);
-        hdr_run += (uint32_t)f.hdr_count;
+        uint64_t slot = 0;
+        bool keep = k < slots && f.hdr_count > 0;
+        if (keep) {
+            // a header is at least two bytes: a count the data cannot hold fails below
+            uint32_t want = (uint32_t)f.hdr_count;
+            if ((uint64_t)want * 2 > rd.len - pos) {
+                keep = false;
+            } else {
+                slot = atomicAdd(hdr_cursor, (unsigned long long)want);
+                if (slot + want > hdr_cap) {
+                    c.status[b] = NISSHI_CAPACITY;
+                    return;
+                }
+                if (hdr_total == 0) first_slot = (uint32_t)slot;
+            }
+        }
+        for (int32_t j = 0; j < f.hdr_count; j++) {
+            uint32_t ko, vo;
+            int32_t kl, vl;
+            if ((st = rd.octets(pos, ko, kl))) break;
+            if ((st = rd.octets(pos, vo, vl))) break;
+            if (keep) {
+                c.hkey_off[slot + j] = ko;
+                c.hkey_len[slot + j] = kl;
+                c.hval_off[slot + j] = vo;
+                c.hval_len[slot + j] = vl;
+            }
+        }
+        if (st) break;
+        if (k < slots) store_record(c, rbase + k, f, (uint32_t)slot);
+        hdr_total += (uint32_t)f.hdr_count;
     }
     c.status[b] = st;
-    c.hdr_count[b] = st == NISSHI_OK ? hdr_run : 0;
+    c.hdr_count[b] = st == NISSHI_OK ? hdr_total : 0;
+    c.hdr_base[b] = first_slot;
 }
 
-// One wave per batch, one lane per record: header spans into the slots
-// hdr_base[b] + (the record's offset within the batch).
-__global__ void headers_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, uint64_t hdr_cap) {
-    uint32_t b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (b >= n) return;
-    if (c.status[b] != NISSHI_OK) return;
-    uint32_t hbase = c.hdr_base[b];
-    uint32_t count = c.record_count[b];
-    uint32_t rbase = c.rec_base[b];
-    if ((uint64_t)hbase + c.hdr_count[b] > hdr_cap) {
-        if (lane == 0) c.status[b] = NISSHI_CAPACITY;
-        return;
-    }
-    const uint8_t *data = blob + c.data_off[b];
-    uint32_t len = c.data_len[b];
-    for (uint32_t k = lane; k < count; k += kWave) {
-        uint32_t r = rbase + k;
-        int32_t hc = c.rhdr_count[r];
-        uint32_t slot = hbase + c.rhdr_base[r];
-        c.rhdr_base[r] = slot;
-        if (hc <= 0) continue;
-        int32_t vl = c.val_len[r];
-        Cursor cur{data, len, c.val_off[r] + (vl > 0 ? (uint32_t)vl : 0u)};
-        int32_t again;
-        read_varint(cur, again);  // the count, already validated by the walk
-        for (int32_t j = 0; j < hc; j++) {
-            uint32_t ko, vo;
-            int32_t kl, vlen;
-            read_octets(cur, ko, kl);
-            read_octets(cur, vo, vlen);
-            c.hkey_off[slot + j] = ko;
-            c.hkey_len[slot + j] = kl;
-            c.hval_off[slot + j] = vo;
-            c.hval_len[slot + j] = vlen;
-        }
+// Totals over batches once every status is final.
+__global__ void finish_kernel(uint32_t n, nisshi_columns c, Work w) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    bool failed = b < n && c.status[b] != NISSHI_OK;
+    bool exact = b < n && (w.flags[b] & kFlagExact);
+    uint64_t fm = __ballot(failed), em = __ballot(exact);
+    if ((threadIdx.x & 63) == 0) {
+        if (fm) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), (unsigned long long)__popcll(fm));
+        if (em) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), (unsigned long long)__popcll(em));
     }
 }
 

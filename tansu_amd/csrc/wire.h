@@ -101,6 +101,87 @@ __device__ __forceinline__ int read_octets(Cursor &c, uint32_t &off, int32_t &le
     return NISSHI_OK;
 }
 
+// A 20-byte window over the record data held in registers, so that the fields
+// of a record that sit next to each other cost one round trip to memory instead
+// of one each.  The window is five aligned dwords; loads never touch a dword
+// that holds no byte of the data (see window64).
+struct Reader {
+    const uint8_t *data;
+    uint32_t len;
+    int32_t wbase;  // position of the window's first byte (may be up to 3 below a valid position)
+    uint32_t d0, d1, d2, d3, d4;
+
+    __device__ __forceinline__ Reader(const uint8_t *data_, uint32_t len_)
+        : data(data_), len(len_), wbase(-1000), d0(0), d1(0), d2(0), d3(0), d4(0) {}
+
+    __device__ __forceinline__ void fill(uint32_t pos) {
+        uintptr_t p = reinterpret_cast<uintptr_t>(data) + pos;
+        uintptr_t last = (reinterpret_cast<uintptr_t>(data) + len - 1) & ~uintptr_t(3);
+        uintptr_t a = p & ~uintptr_t(3);
+        wbase = (int32_t)pos - (int32_t)(p & 3);
+        a = a <= last ? a : last;
+        d0 = *reinterpret_cast<const uint32_t *>(a);
+        d1 = *reinterpret_cast<const uint32_t *>(a + 4 <= last ? a + 4 : last);
+        d2 = *reinterpret_cast<const uint32_t *>(a + 8 <= last ? a + 8 : last);
+        d3 = *reinterpret_cast<const uint32_t *>(a + 12 <= last ? a + 12 : last);
+        d4 = *reinterpret_cast<const uint32_t *>(a + 16 <= last ? a + 16 : last);
+    }
+
+    // eight bytes starting at pos (pos < len)
+    __device__ __forceinline__ uint64_t get64(uint32_t pos) {
+        int32_t o = (int32_t)pos - wbase;
+        if (o < 0 || o > 11) {
+            fill(pos);
+            o = (int32_t)pos - wbase;
+        }
+        uint32_t q = (uint32_t)o >> 2, r = (uint32_t)o & 3;
+        uint32_t x0 = q == 0 ? d0 : q == 1 ? d1 : d2;
+        uint32_t x1 = q == 0 ? d1 : q == 1 ? d2 : d3;
+        uint32_t x2 = q == 0 ? d2 : q == 1 ? d3 : d4;
+        uint32_t lo = __builtin_amdgcn_alignbyte(x1, x0, r);
+        uint32_t hi = __builtin_amdgcn_alignbyte(x2, x1, r);
+        return ((uint64_t)hi << 32) | lo;
+    }
+
+    __device__ __forceinline__ int varint(uint32_t &pos, int32_t &out) {
+        if (pos >= len) return NISSHI_TRY_GET;
+        uint32_t used = 0;
+        int st = varint32(get64(pos), len - pos, used, out);
+        pos += used;
+        return st;
+    }
+
+    __device__ inline int varlong(uint32_t &pos, int64_t &out) {
+        if (pos >= len) return NISSHI_TRY_GET;
+        uint32_t avail = len - pos;
+        uint64_t acc = 0;
+        uint64_t w = get64(pos);
+        for (int i = 0; i < 11; i++) {
+            if ((uint32_t)i >= avail) return NISSHI_TRY_GET;
+            if (i == 10) return NISSHI_OVERFLOW;
+            if (i == 8) w = get64(pos + 8);
+            uint32_t b = (uint32_t)(w >> (8 * (i & 7))) & 0xffu;
+            acc |= (uint64_t)(b & 0x7fu) << (7 * i);
+            if (!(b & 0x80u)) {
+                pos += i + 1;
+                out = (int64_t)(acc >> 1) ^ -(int64_t)(acc & 1u);
+                return NISSHI_OK;
+            }
+        }
+        return NISSHI_OVERFLOW;
+    }
+
+    __device__ __forceinline__ int octets(uint32_t &pos, uint32_t &off, int32_t &n) {
+        int st = varint(pos, n);
+        if (st) return st;
+        off = pos;
+        if (n == -1) return NISSHI_OK;
+        if (n < 0 || (uint32_t)n > len - pos) return NISSHI_MALFORMED;
+        pos += (uint32_t)n;
+        return NISSHI_OK;
+    }
+};
+
 struct RecordFields {
     int32_t length;
     uint32_t attributes;
@@ -133,6 +214,23 @@ __device__ inline int read_record(Cursor &c, RecordFields &r) {
         if ((st = read_octets(c, off, len))) return st;
         if ((st = read_octets(c, off, len))) return st;
     }
+    return NISSHI_OK;
+}
+
+// Record::decode up to and including the header count; pos ends on the first header.
+__device__ inline int read_record_head(Reader &rd, uint32_t &pos, RecordFields &r) {
+    int st;
+    if ((st = rd.varint(pos, r.length))) return st;
+    if (pos >= rd.len) return NISSHI_MALFORMED;  // get_u8 on an empty buffer panics
+    r.attributes = (uint32_t)rd.get64(pos) & 0xffu;
+    pos += 1;
+    if ((st = rd.varlong(pos, r.timestamp_delta))) return st;
+    if ((st = rd.varint(pos, r.offset_delta))) return st;
+    if ((st = rd.octets(pos, r.key_off, r.key_len))) return st;
+    if ((st = rd.octets(pos, r.val_off, r.val_len))) return st;
+    if ((st = rd.varint(pos, r.hdr_count))) return st;
+    if (r.hdr_count < 0) return NISSHI_MALFORMED;  // Vec::with_capacity(huge) panics
+    r.hdr_pos = pos;
     return NISSHI_OK;
 }
 

@@ -9,12 +9,11 @@ import pytest
 
 import oracle
 from tansu_amd import columns as C, hip, synth
-from util import find_batches, load_vectors, offsets_of, record_from_json
+from util import assert_same, find_batches, load_vectors, offsets_of, record_from_json
 
 pytestmark = pytest.mark.gpu
 
 V = load_vectors()
-BATCH_FIELDS = [n for n, _ in C.BATCH_COLUMNS if n not in ("rec_base", "hdr_base", "hdr_count")]
 
 
 @pytest.fixture(scope="module")
@@ -33,28 +32,6 @@ def gpu_decode(codec, blob, off, by_value=True, rec_cap=None, hdr_cap=None):
     cols = hip.DeviceColumns(n_b, rec_cap, hdr_cap, codec.device)
     totals = codec.decode_dev(d_blob, len(blob), d_off, n_b, cols, by_value)
     return cols, totals, d_blob, d_off
-
-
-def assert_same(gpu: dict, cpu: dict, n_batches: int):
-    """Compare decoded columns batch by batch (a failed batch may leave unused
-    record slots on the GPU side, so indices are taken from rec_base)."""
-    for name in BATCH_FIELDS:
-        assert (gpu[name][:n_batches] == cpu[name][:n_batches]).all(), name
-    ok = cpu["status"][:n_batches] == C.OK
-    assert (gpu["hdr_count"][:n_batches][ok] == cpu["hdr_count"][:n_batches][ok]).all()
-    rec_names = [n for n, _ in C.RECORD_COLUMNS if n != "rhdr_base"]
-    hdr_names = [n for n, _ in C.HEADER_COLUMNS]
-    for b in np.flatnonzero(ok):
-        n = int(cpu["record_count"][b])
-        g0, c0 = int(gpu["rec_base"][b]), int(cpu["rec_base"][b])
-        for name in rec_names:
-            assert (gpu[name][g0:g0 + n] == cpu[name][c0:c0 + n]).all(), (int(b), name)
-        nh = int(cpu["hdr_count"][b])
-        if nh:
-            gh, ch = int(gpu["hdr_base"][b]), int(cpu["hdr_base"][b])
-            assert (gpu["rhdr_base"][g0:g0 + n] - gh == cpu["rhdr_base"][c0:c0 + n] - ch).all()
-            for name in hdr_names:
-                assert (gpu[name][gh:gh + nh] == cpu[name][ch:ch + nh]).all(), (int(b), name)
 
 
 def check_against_oracle(codec, blob, off, by_value=True):
@@ -187,7 +164,8 @@ def test_synthetic_vs_oracle(codec, name, scale):
     crc_patch(codec, blob, off)
     g, c, totals, cols, d_blob, d_off = check_against_oracle(codec, blob, off)
     assert totals.n_failed == 0 and totals.n_exact == 0
-    assert (totals.n_records, totals.n_headers) == (nr, nh)
+    assert totals.n_records == nr and nh <= totals.n_headers <= nh + 4096 * len(counts)
+    assert int(g["hdr_count"].sum()) == nh
     assert (g["crc"] == g["crc_computed"]).all()
     # re-encode on the GPU equals the oracle's re-encode and the (canonical) input
     import torch
@@ -321,7 +299,7 @@ def test_capacity_is_reported(codec):
     assert st[-1] == C.CAPACITY and (st[:-1] == C.OK).all() and totals.n_failed == 1
     cols, totals, *_ = gpu_decode(codec, blob, off, rec_cap=nr, hdr_cap=nh - 1)
     st = cols.to_host(0, 0)["status"]
-    assert st[-1] == C.CAPACITY and totals.n_headers == nh
+    assert (st == C.CAPACITY).sum() == 1 and totals.n_failed == 1 and totals.n_headers >= nh
 
 
 def test_empty_call(codec):
@@ -348,6 +326,7 @@ def test_full_size_properties(codec, name):
     n_b = len(counts)
     cols, totals, d_blob, d_off = gpu_decode(codec, blob, off, rec_cap=nr, hdr_cap=max(nh, 1))
     assert (totals.n_records, totals.n_headers, totals.n_failed, totals.n_exact) == (nr, nh, 0, 0)
+    assert int(cols.t["hdr_count"].sum()) == nh
     t = cols.t
     assert bool((t["status"] == 0).all()) and bool((t["crc"] == t["crc_computed"]).all())
     r = int(counts[0])
@@ -356,8 +335,10 @@ def test_full_size_properties(codec, name):
     assert bool((t["timestamp_delta"][:nr].view(n_b, r) == torch.arange(r, device=od.device)).all())
     assert bool((t["val_len"][:nr] == shape.val_len).all()) and bool((t["key_len"][:nr] == shape.key_len).all())
     if nh:
-        assert bool((t["hkey_len"][:nh] == shape.hkey_len).all())
-        assert bool((t["rhdr_base"][:nr] == torch.arange(nr, device=od.device, dtype=torch.int32) * shape.n_headers).all())
+        # uniform batches use exactly their header count; every record owns its own run of slots
+        assert bool((t["hkey_len"][:nh] == shape.hkey_len).all()) and bool((t["hval_len"][:nh] == shape.hval_len).all())
+        base = t["rhdr_base"][:nr].to(torch.int64).sort().values
+        assert bool((base == torch.arange(nr, device=od.device) * shape.n_headers).all())
     # one batch in full against the oracle
     b = n_b // 3
     sub = blob[int(off[b]):int(off[b + 1])]

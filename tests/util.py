@@ -47,3 +47,42 @@ def offsets_of(batches):
     for i, b in enumerate(batches):
         off[i + 1] = off[i] + len(b)
     return off
+
+
+BATCH_FIELDS = [n for n, _ in C.BATCH_COLUMNS if n not in ("rec_base", "hdr_base", "hdr_count")]
+
+
+def header_slots(base, count):
+    """Indices of every header of every record, in record order."""
+    count = np.maximum(count.astype(np.int64), 0)
+    total = int(count.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.int64)
+    starts = np.repeat(base.astype(np.int64), count)
+    first = np.repeat(np.cumsum(count) - count, count)
+    return starts + (np.arange(total, dtype=np.int64) - first)
+
+
+def assert_same(gpu: dict, cpu: dict, n_batches: int):
+    """Compare decoded columns batch by batch.  A failed batch may leave unused
+    record slots on the GPU side, and header slots are handed out in runs whose
+    order is not defined, so records are located through rec_base and headers
+    through each record's rhdr_base."""
+    for name in BATCH_FIELDS:
+        assert (gpu[name][:n_batches] == cpu[name][:n_batches]).all(), name
+    ok = cpu["status"][:n_batches] == C.OK
+    assert (gpu["hdr_count"][:n_batches][ok] == cpu["hdr_count"][:n_batches][ok]).all()
+    rec_names = [n for n, _ in C.RECORD_COLUMNS if n != "rhdr_base"]
+    hdr_names = [n for n, _ in C.HEADER_COLUMNS]
+    counts = cpu["record_count"][:n_batches][ok].astype(np.int64)
+    gi = header_slots(gpu["rec_base"][:n_batches][ok], counts)   # record indices, GPU side
+    ci = header_slots(cpu["rec_base"][:n_batches][ok], counts)
+    for name in rec_names:
+        assert (gpu[name][gi] == cpu[name][ci]).all(), name
+    gh = header_slots(gpu["rhdr_base"][gi], gpu["rhdr_count"][gi])
+    ch = header_slots(cpu["rhdr_base"][ci], cpu["rhdr_count"][ci])
+    assert len(np.unique(gh)) == len(gh)                      # no slot is shared
+    for name in hdr_names:
+        assert (gpu[name][gh] == cpu[name][ch]).all(), name
+
+
