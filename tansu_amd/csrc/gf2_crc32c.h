@@ -196,23 +196,32 @@ __device__ inline uint32_t crc_rows(const uint8_t *base, uint64_t grid, uint64_t
 }
 
 
-// Incremental form of crc_rows for a wave that interleaves the CRC with other
-// work on the same bytes: rows are consumed in order, a few loads in flight at a
-// time, so that what the wave parses next has just been fetched.
-struct CrcStream {
+// A wave's pass over one batch: rows are fetched in order with coalesced 16-byte
+// loads, a few in flight at a time, folded into the CRC accumulator and copied
+// raw into a ring of the last kRingRows rows in LDS, from which the same wave
+// then parses records.  The batch is read from HBM once.
+constexpr int kRingRows = 8;
+constexpr int kRingBytes = kRingRows * kRowBytes;
+constexpr int kRingGuard = 64;  // the ring's first bytes again, so a window may run past the end
+constexpr int kRingWords = (kRingBytes + kRingGuard) / 4;
+
+struct BatchStream {
     const uint8_t *base;
     uint64_t grid, lo, hi;
     uint32_t rows, next_row;
     uint32_t acc[4];
+    uint32_t *ring;
     int lane;
 
-    __device__ __forceinline__ void init(const uint8_t *base_, uint64_t lo_, uint64_t hi_, int lane_) {
+    __device__ __forceinline__ void init(const uint8_t *base_, uint64_t lo_, uint64_t hi_,
+                                         uint32_t *ring_, int lane_) {
         base = base_;
         lo = lo_;
         hi = hi_;
         grid = lo_ & ~uint64_t(15);
         rows = (uint32_t)((hi_ - grid + kRowBytes - 1) / kRowBytes);
         next_row = 0;
+        ring = ring_;
         lane = lane_;
         acc[0] = acc[1] = acc[2] = acc[3] = 0;
     }
@@ -224,27 +233,29 @@ struct CrcStream {
         return r < rows ? (uint32_t)r : rows;
     }
 
-    __device__ __forceinline__ void load(uint32_t r, uint32_t (&nx)[4]) const {
+    __device__ __forceinline__ uint4 fetch(uint32_t r) const {
         uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
-        nx[0] = nx[1] = nx[2] = nx[3] = 0;
-        if (addr + 16 > lo && addr < hi) {
-            uint4 v = *reinterpret_cast<const uint4 *>(base + addr);
-            nx[0] = v.x;
-            nx[1] = v.y;
-            nx[2] = v.z;
-            nx[3] = v.w;
-            if (addr < lo || addr + 16 > hi) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (addr + 16 > lo && addr < hi) v = *reinterpret_cast<const uint4 *>(base + addr);
+        return v;
+    }
+
+    __device__ __forceinline__ void take(uint4 v, uint32_t r) {
+        // raw bytes into the ring (bytes outside [lo, hi) in the edge words are never parsed)
+        uint32_t slot = r & (kRingRows - 1);
+        *reinterpret_cast<uint4 *>(ring + slot * (kRowBytes / 4) + lane * 4) = v;
+        if (slot == 0 && lane < kRingGuard / 16)
+            *reinterpret_cast<uint4 *>(ring + kRingBytes / 4 + lane * 4) = v;
+        uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
+        uint32_t nx[4] = {v.x, v.y, v.z, v.w};
+        if (addr < lo || addr + 16 > hi) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) nx[i] &= byte_mask(addr + 4 * i, lo, hi);
-            }
+            for (int i = 0; i < 4; i++) nx[i] &= byte_mask(addr + 4 * i, lo, hi);
         }
-        if (addr + 16 > lo && addr < lo + 4) {
+        if (addr + 16 > lo && addr < lo + 4) {  // the 0xFFFFFFFF initial value
 #pragma unroll
             for (int i = 0; i < 4; i++) nx[i] ^= byte_mask(addr + 4 * i, lo, lo + 4);
         }
-    }
-
-    __device__ __forceinline__ void take(const uint32_t (&nx)[4], uint32_t r) {
         if (r == 0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[i] = nx[i];
@@ -254,25 +265,33 @@ struct CrcStream {
     }
 
     // consume rows up to (not including) `target`
-    __device__ inline void advance(uint32_t target) {
+    __device__ __forceinline__ void advance(uint32_t target) {
         if (target > rows) target = rows;
         while (next_row < target) {
             uint32_t nb = target - next_row;
-            uint32_t n0[4], n1[4], n2[4], n3[4];
-            load(next_row, n0);
-            if (nb > 1) load(next_row + 1, n1);
-            if (nb > 2) load(next_row + 2, n2);
-            if (nb > 3) load(next_row + 3, n3);
-            take(n0, next_row);
-            if (nb > 1) take(n1, next_row + 1);
-            if (nb > 2) take(n2, next_row + 2);
-            if (nb > 3) take(n3, next_row + 3);
+            uint4 v0 = fetch(next_row), v1, v2, v3;
+            if (nb > 1) v1 = fetch(next_row + 1);
+            if (nb > 2) v2 = fetch(next_row + 2);
+            if (nb > 3) v3 = fetch(next_row + 3);
+            take(v0, next_row);
+            if (nb > 1) take(v1, next_row + 1);
+            if (nb > 2) take(v2, next_row + 2);
+            if (nb > 3) take(v3, next_row + 3);
             next_row += nb < 4 ? nb : 4;
         }
     }
 
+    // bytes currently in the ring, as absolute offsets [from, to)
+    __device__ __forceinline__ uint64_t staged_from() const {
+        uint32_t first = next_row > (uint32_t)kRingRows ? next_row - kRingRows : 0;
+        return grid + (uint64_t)first * kRowBytes;
+    }
+    __device__ __forceinline__ uint64_t staged_to() const {
+        return grid + (uint64_t)next_row * kRowBytes;
+    }
+
     // the CRC-32C of [lo, hi)
-    __device__ inline uint32_t finish(const CrcTables *t) {
+    __device__ __forceinline__ uint32_t finish(const CrcTables *t) {
         advance(rows);
         if (hi == lo) return 0;
         uint32_t r = crc_row_residue(acc, lane, t);

@@ -272,34 +272,58 @@ constexpr uint32_t kHdrRunMax = 4096;
 // be walked sequentially (exact_kernel): a length that disagrees with the fields
 // it describes, or any decode error.
 //
-// Record starts are found 64 at a time by speculation: lane i assumes that the
-// i-th next record starts i * S bytes on, S being the size of the record before,
-// and decodes the length varint there.  Lanes up to and including the first one
-// whose size differs from S did start on a record, and the walk resumes after
-// that lane's record.  Batches of equal-sized records resolve 64 records per
-// step, ragged ones at least one.  Each resolved record is then decoded by its
-// lane and must end where its length said.
-__device__ inline bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
-                                  const Work &w, uint64_t hdr_cap, CrcStream *crc, int lane) {
+// Record starts are found up to 64 at a time by speculation: lane i assumes that
+// the i-th next record starts i * S bytes on, S being the size of the record
+// before, and decodes the length varint there.  Lanes up to and including the
+// first one whose size differs from S did start on a record, and the walk
+// resumes after that lane's record.  Batches of equal-sized records resolve 64
+// records per step, ragged ones at least one.  Each resolved record is then
+// decoded by its lane and must end where its length said.
+//
+// With `stream` the wave first pulls the rows it is about to parse through the
+// CRC and into its LDS ring, and the parse reads LDS; records that do not fit
+// the ring are read from global memory.
+__device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
+                                           const Work &w, uint64_t hdr_cap, BatchStream &stream,
+                                           bool streaming, int lane) {
     uint32_t count = c.record_count[b];
     uint32_t rbase = c.rec_base[b];
     uint64_t data_off = c.data_off[b];
     Reader rd(blob + data_off, c.data_len[b]);
+    if (streaming) {
+        rd.ring = stream.ring;
+        rd.ring_bias = (uint32_t)(data_off - stream.grid);
+        rd.ring_mask = kRingBytes - 1;
+    }
     unsigned long long *hdr_cursor = reinterpret_cast<unsigned long long *>(w.totals + 1);
     uint64_t run_pos = 0, run_end = 0;  // header slots in hand
     uint32_t hdr_total = 0, first_slot = 0;
     uint32_t pos = 0;
     uint32_t S = count ? rd.len / count : 0;
+    // with a ring, speculate only as far as the ring reaches
+    constexpr uint32_t kReach = kRingBytes - 2 * kRowBytes;
     for (uint32_t k = 0; k < count;) {
         uint32_t m = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
         uint32_t found = 0, my_start = 0, my_size = 0;
+        uint32_t round_start = pos;
         while (found < m) {
-            if (crc) crc->advance(crc->row_after(data_off + pos + (uint64_t)(m - found) * S + 64));
+            uint32_t lanes = m - found;
+            if (streaming) {
+                if ((uint64_t)lanes * S > kReach) lanes = S ? kReach / S : 1;
+                if (lanes == 0) lanes = 1;
+                if (pos + (uint64_t)lanes * S + 64 - round_start > kReach && found) break;
+                stream.advance(stream.row_after(data_off + pos + (uint64_t)lanes * S + 64));
+                __syncthreads();
+                uint64_t from = stream.staged_from(), to = stream.staged_to();
+                rd.win_lo = from > data_off ? (uint32_t)(from - data_off) : 0;
+                rd.win_hi = to > data_off ? (uint32_t)(to - data_off) : 0;
+                rd.wbase = -1000;
+            }
             uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
             uint32_t guess = guess64 < rd.len ? (uint32_t)guess64 : rd.len;
             uint32_t p = guess;
             int32_t len = 0;
-            int st = rd.varint(p, len);
+            int st = (uint32_t)lane < lanes ? rd.varint(p, len) : NISSHI_TRY_GET;
             bool ok = st == NISSHI_OK && len >= 0 && (uint32_t)len <= rd.len - p;
             uint32_t size = ok ? p - guess + (uint32_t)len : 0;
             uint64_t okmask = __ballot(ok);
@@ -308,7 +332,7 @@ __device__ inline bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_
             uint32_t good = ~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64;
             uint32_t v = good;  // lanes below `good` are records of size S
             if (good < 64 && ((okmask >> good) & 1)) v = good + 1;
-            if (v > m - found) v = m - found;
+            if (v > lanes) v = lanes;
             int src = lane - (int)found;
             uint32_t s_start = __shfl(guess, src & 63, 64);
             uint32_t s_size = __shfl(size, src & 63, 64);
@@ -320,6 +344,7 @@ __device__ inline bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_
             pos = __shfl(guess, (int)v - 1, 64) + S;
             found += v;
         }
+        m = found;
         // ---- one lane per record
         RecordFields f;
         bool live = (uint32_t)lane < m;
@@ -376,6 +401,7 @@ __device__ inline bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_
         if (__any(bad)) return false;
         if (live) store_record(c, rbase + k + lane, f, (uint32_t)slot);
         k += m;
+        __syncthreads();  // every lane is done with the ring before it moves on
     }
     if (lane == 0) {
         c.hdr_count[b] = hdr_total;
@@ -385,15 +411,16 @@ __device__ inline bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_
 }
 
 // One wave per batch: CRC-32C of the batch streamed just ahead of the record
-// walk, so the bytes the walk gathers have just come through the cache, and the
-// batch is read from HBM once.  Batches of kBigChunks chunks or more get their
-// CRC from crc_chunks_kernel instead (one wave cannot stream them fast enough).
+// walk through an LDS ring, so the batch is read from HBM once.  Batches of
+// kBigChunks chunks or more get their CRC from crc_chunks_kernel instead (one
+// wave cannot stream them fast enough) and are parsed from global memory.
 constexpr uint32_t kBigChunks = 8;
 
 __global__ __launch_bounds__(64) void decode_fused_kernel(const uint8_t *blob,
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
                                                           uint64_t hdr_cap, const CrcTables *t) {
+    __shared__ __attribute__((aligned(16))) uint32_t ring[kRingWords];
     uint32_t b = blockIdx.x;
     int lane = threadIdx.x;
     if (b >= n) return;
@@ -404,16 +431,14 @@ __global__ __launch_bounds__(64) void decode_fused_kernel(const uint8_t *blob,
         if (lane == 0) c.status[b] = NISSHI_CAPACITY;
         do_walk = false;
     }
-    CrcStream crc;
-    if (do_crc) {
-        uint64_t lo = batch_off[b] + 21;
-        crc.init(blob, lo, lo + (uint64_t)c.batch_length[b] - 9, lane);
-    }
-    if (do_walk && !walk_batch(blob, b, c, w, hdr_cap, do_crc ? &crc : nullptr, lane)) {
+    BatchStream stream;
+    uint64_t lo = batch_off[b] + 21;
+    stream.init(blob, lo, do_crc ? lo + (uint64_t)c.batch_length[b] - 9 : lo, ring, lane);
+    if (do_walk && !walk_batch(blob, b, c, w, hdr_cap, stream, do_crc, lane)) {
         if (lane == 0) w.flags[b] |= kFlagExact;
     }
     if (do_crc) {
-        uint32_t v = crc.finish(t);
+        uint32_t v = stream.finish(t);
         if (lane == 0) c.crc_computed[b] = v;
     }
 }

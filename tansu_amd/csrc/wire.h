@@ -54,67 +54,40 @@ __device__ __forceinline__ int varint32(uint64_t w, uint32_t avail, uint32_t &us
     return avail <= 5 ? NISSHI_TRY_GET : NISSHI_OVERFLOW;
 }
 
-struct Cursor {
-    const uint8_t *data;  // the batch's record_data
-    uint32_t len;
-    uint32_t pos;
-};
-
-__device__ __forceinline__ int read_varint(Cursor &c, int32_t &out) {
-    if (c.pos >= c.len) return NISSHI_TRY_GET;
-    uint32_t used = 0;
-    int st = varint32(window64(c.data, c.pos, c.len), c.len - c.pos, used, out);
-    c.pos += used;
-    return st;
-}
-
-// LongVarInt::decode: up to ten bytes, the eleventh overflows.
-__device__ inline int read_varlong(Cursor &c, int64_t &out) {
-    uint64_t acc = 0;
-    uint32_t avail = c.len - c.pos;
-    if (c.pos >= c.len) return NISSHI_TRY_GET;
-    uint64_t w = window64(c.data, c.pos, c.len);
-    for (int i = 0; i < 11; i++) {
-        if ((uint32_t)i >= avail) return NISSHI_TRY_GET;
-        if (i == 10) return NISSHI_OVERFLOW;
-        if (i == 8) w = window64(c.data, c.pos + 8, c.len);
-        uint32_t b = (uint32_t)(w >> (8 * (i & 7))) & 0xffu;
-        acc |= (uint64_t)(b & 0x7fu) << (7 * i);  // i == 9: only bit 63 survives
-        if (!(b & 0x80u)) {
-            c.pos += i + 1;
-            out = (int64_t)(acc >> 1) ^ -(int64_t)(acc & 1u);
-            return NISSHI_OK;
-        }
-    }
-    return NISSHI_OVERFLOW;
-}
-
-// Octets::decode: -1 is None; any other negative length, or one past the end,
-// panics in Bytes::split_to.
-__device__ __forceinline__ int read_octets(Cursor &c, uint32_t &off, int32_t &len) {
-    int st = read_varint(c, len);
-    if (st) return st;
-    off = c.pos;
-    if (len == -1) return NISSHI_OK;
-    if (len < 0 || (uint32_t)len > c.len - c.pos) return NISSHI_MALFORMED;
-    c.pos += (uint32_t)len;
-    return NISSHI_OK;
-}
-
 // A 20-byte window over the record data held in registers, so that the fields
 // of a record that sit next to each other cost one round trip to memory instead
 // of one each.  The window is five aligned dwords; loads never touch a dword
 // that holds no byte of the data (see window64).
+//
+// When the wave has staged a stretch of the batch in LDS (BatchStream), windows
+// inside [win_lo, win_hi) are read from there; anything else comes from global
+// memory.  `ring_bias` is the distance of the record data from the ring's grid
+// origin, which is 16-byte aligned like the blob, so byte alignment agrees.
 struct Reader {
     const uint8_t *data;
     uint32_t len;
     int32_t wbase;  // position of the window's first byte (may be up to 3 below a valid position)
     uint32_t d0, d1, d2, d3, d4;
+    const uint32_t *ring;
+    uint32_t ring_bias, ring_mask;
+    uint32_t win_lo, win_hi;
 
     __device__ __forceinline__ Reader(const uint8_t *data_, uint32_t len_)
-        : data(data_), len(len_), wbase(-1000), d0(0), d1(0), d2(0), d3(0), d4(0) {}
+        : data(data_), len(len_), wbase(-1000), d0(0), d1(0), d2(0), d3(0), d4(0), ring(nullptr),
+          ring_bias(0), ring_mask(0), win_lo(0), win_hi(0) {}
 
     __device__ __forceinline__ void fill(uint32_t pos) {
+        if (pos >= win_lo && pos + 20 <= win_hi) {
+            uint32_t o = pos + ring_bias;
+            wbase = (int32_t)pos - (int32_t)(o & 3);
+            const uint32_t *q = ring + ((o & ring_mask) >> 2);
+            d0 = q[0];
+            d1 = q[1];
+            d2 = q[2];
+            d3 = q[3];
+            d4 = q[4];
+            return;
+        }
         uintptr_t p = reinterpret_cast<uintptr_t>(data) + pos;
         uintptr_t last = (reinterpret_cast<uintptr_t>(data) + len - 1) & ~uintptr_t(3);
         uintptr_t a = p & ~uintptr_t(3);
@@ -134,12 +107,15 @@ struct Reader {
             fill(pos);
             o = (int32_t)pos - wbase;
         }
+        // shift every adjacent pair, then pick by dword offset: selecting among
+        // computed values keeps the window in registers
         uint32_t q = (uint32_t)o >> 2, r = (uint32_t)o & 3;
-        uint32_t x0 = q == 0 ? d0 : q == 1 ? d1 : d2;
-        uint32_t x1 = q == 0 ? d1 : q == 1 ? d2 : d3;
-        uint32_t x2 = q == 0 ? d2 : q == 1 ? d3 : d4;
-        uint32_t lo = __builtin_amdgcn_alignbyte(x1, x0, r);
-        uint32_t hi = __builtin_amdgcn_alignbyte(x2, x1, r);
+        uint32_t a01 = __builtin_amdgcn_alignbyte(d1, d0, r);
+        uint32_t a12 = __builtin_amdgcn_alignbyte(d2, d1, r);
+        uint32_t a23 = __builtin_amdgcn_alignbyte(d3, d2, r);
+        uint32_t a34 = __builtin_amdgcn_alignbyte(d4, d3, r);
+        uint32_t lo = q == 0 ? a01 : q == 1 ? a12 : a23;
+        uint32_t hi = q == 0 ? a12 : q == 1 ? a23 : a34;
         return ((uint64_t)hi << 32) | lo;
     }
 
@@ -151,7 +127,7 @@ struct Reader {
         return st;
     }
 
-    __device__ inline int varlong(uint32_t &pos, int64_t &out) {
+    __device__ __forceinline__ int varlong(uint32_t &pos, int64_t &out) {
         if (pos >= len) return NISSHI_TRY_GET;
         uint32_t avail = len - pos;
         uint64_t acc = 0;
@@ -193,32 +169,8 @@ struct RecordFields {
     uint32_t hdr_pos;  // position of the first header, after the count
 };
 
-// Record::decode.  Walks the headers to find where the record ends; the header
-// spans themselves are extracted in a later pass once their slots are known.
-__device__ inline int read_record(Cursor &c, RecordFields &r) {
-    int st;
-    if ((st = read_varint(c, r.length))) return st;
-    if (c.pos >= c.len) return NISSHI_MALFORMED;  // get_u8 on an empty buffer panics
-    r.attributes = c.data[c.pos];
-    c.pos += 1;
-    if ((st = read_varlong(c, r.timestamp_delta))) return st;
-    if ((st = read_varint(c, r.offset_delta))) return st;
-    if ((st = read_octets(c, r.key_off, r.key_len))) return st;
-    if ((st = read_octets(c, r.val_off, r.val_len))) return st;
-    if ((st = read_varint(c, r.hdr_count))) return st;
-    if (r.hdr_count < 0) return NISSHI_MALFORMED;  // Vec::with_capacity(huge) panics
-    r.hdr_pos = c.pos;
-    for (int32_t i = 0; i < r.hdr_count; i++) {
-        uint32_t off;
-        int32_t len;
-        if ((st = read_octets(c, off, len))) return st;
-        if ((st = read_octets(c, off, len))) return st;
-    }
-    return NISSHI_OK;
-}
-
 // Record::decode up to and including the header count; pos ends on the first header.
-__device__ inline int read_record_head(Reader &rd, uint32_t &pos, RecordFields &r) {
+__device__ __forceinline__ int read_record_head(Reader &rd, uint32_t &pos, RecordFields &r) {
     int st;
     if ((st = rd.varint(pos, r.length))) return st;
     if (pos >= rd.len) return NISSHI_MALFORMED;  // get_u8 on an empty buffer panics
