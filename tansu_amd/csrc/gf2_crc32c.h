@@ -99,6 +99,15 @@ __device__ inline uint32_t gf_xpow8(const CrcTables *t, uint64_t n) {
     return r;
 }
 
+// Tell the compiler a value is the same in every lane, so that it lives in a
+// scalar register and branches on it are scalar branches.
+__device__ __forceinline__ uint32_t uni(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+
 __device__ __forceinline__ uint32_t fsh(uint32_t hi, uint32_t lo, int r) {
     return __builtin_amdgcn_alignbit(hi, lo, r);  // ({hi,lo} >> r)[31:0]
 }
@@ -204,23 +213,34 @@ constexpr int kRingRows = 8;
 constexpr int kRingBytes = kRingRows * kRowBytes;
 constexpr int kRingGuard = 64;  // the ring's first bytes again, so a window may run past the end
 constexpr int kRingWords = (kRingBytes + kRingGuard) / 4;
+constexpr int kPrefetchRows = 8;
+// pointers into LDS keep their address space, so that accesses are ds_read /
+// ds_write and not flat instructions
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u128;
 
 struct BatchStream {
     const uint8_t *base;
     uint64_t grid, lo, hi;
     uint32_t rows, next_row;
     uint32_t acc[4];
-    uint32_t *ring;
+    lds_u32 *ring;
     int lane;
+    int dbg;
+    // rows fetched ahead of time and not yet folded or staged (see prefetch)
+    uint4 pend[kPrefetchRows];
+    uint32_t pend_n;
 
     __device__ __forceinline__ void init(const uint8_t *base_, uint64_t lo_, uint64_t hi_,
-                                         uint32_t *ring_, int lane_) {
+                                         lds_u32 *ring_, int lane_) {
         base = base_;
-        lo = lo_;
-        hi = hi_;
-        grid = lo_ & ~uint64_t(15);
-        rows = (uint32_t)((hi_ - grid + kRowBytes - 1) / kRowBytes);
+        lo = uni64(lo_);
+        hi = uni64(hi_);
+        grid = lo & ~uint64_t(15);
+        rows = (uint32_t)((hi - grid + kRowBytes - 1) / kRowBytes);
         next_row = 0;
+        pend_n = 0;
         ring = ring_;
         lane = lane_;
         acc[0] = acc[1] = acc[2] = acc[3] = 0;
@@ -233,8 +253,12 @@ struct BatchStream {
         return r < rows ? (uint32_t)r : rows;
     }
 
+    __device__ __forceinline__ bool edge(uint32_t r) const { return r == 0 || r + 1 == rows; }
+
     __device__ __forceinline__ uint4 fetch(uint32_t r) const {
         uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
+        // rows between the first and the last lie wholly inside [lo, hi)
+        if (!edge(r)) return *reinterpret_cast<const uint4 *>(base + addr);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (addr + 16 > lo && addr < hi) v = *reinterpret_cast<const uint4 *>(base + addr);
         return v;
@@ -243,30 +267,59 @@ struct BatchStream {
     __device__ __forceinline__ void take(uint4 v, uint32_t r) {
         // raw bytes into the ring (bytes outside [lo, hi) in the edge words are never parsed)
         uint32_t slot = r & (kRingRows - 1);
-        *reinterpret_cast<uint4 *>(ring + slot * (kRowBytes / 4) + lane * 4) = v;
-        if (slot == 0 && lane < kRingGuard / 16)
-            *reinterpret_cast<uint4 *>(ring + kRingBytes / 4 + lane * 4) = v;
-        uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
+        u32x4 raw = {v.x, v.y, v.z, v.w};
+        *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4) = raw;
+        if (slot == 0 && lane < kRingGuard / 16) *(lds_u128 *)(ring + kRingBytes / 4 + lane * 4) = raw;
         uint32_t nx[4] = {v.x, v.y, v.z, v.w};
-        if (addr < lo || addr + 16 > hi) {
+        if (edge(r)) {
+            uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
+            if (addr < lo || addr + 16 > hi) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) nx[i] &= byte_mask(addr + 4 * i, lo, hi);
-        }
-        if (addr + 16 > lo && addr < lo + 4) {  // the 0xFFFFFFFF initial value
+                for (int i = 0; i < 4; i++) nx[i] &= byte_mask(addr + 4 * i, lo, hi);
+            }
+            if (addr + 16 > lo && addr < lo + 4) {  // the 0xFFFFFFFF initial value
 #pragma unroll
-            for (int i = 0; i < 4; i++) nx[i] ^= byte_mask(addr + 4 * i, lo, lo + 4);
+                for (int i = 0; i < 4; i++) nx[i] ^= byte_mask(addr + 4 * i, lo, lo + 4);
+            }
         }
         if (r == 0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[i] = nx[i];
+        } else if (dbg & 2) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] ^= nx[i];
         } else {
             crc_fold_row(acc, nx, lane);
         }
     }
 
-    // consume rows up to (not including) `target`
-    __device__ __forceinline__ void advance(uint32_t target) {
+    // Issue the loads of the rows up to `target` (at most kPrefetchRows of them) and
+    // return at once: the data is folded and staged by the next advance, after the
+    // wave has spent the latency parsing what is already in the ring.
+    __device__ __forceinline__ void prefetch(uint32_t target) {
+        target = uni(target);
         if (target > rows) target = rows;
+        if (pend_n || target <= next_row) return;
+        uint32_t n = target - next_row;
+        if (n > (uint32_t)kPrefetchRows) n = kPrefetchRows;
+#pragma unroll
+        for (int j = 0; j < kPrefetchRows; j++)
+            if ((uint32_t)j < n) pend[j] = fetch(next_row + j);
+        pend_n = n;
+    }
+
+    // consume rows up to (not including) `target`; rows already prefetched are
+    // consumed even when they lie beyond it
+    __device__ __forceinline__ void advance(uint32_t target) {
+        target = uni(target);
+        if (target > rows) target = rows;
+        if (pend_n) {
+#pragma unroll
+            for (int j = 0; j < kPrefetchRows; j++)
+                if ((uint32_t)j < pend_n) take(pend[j], next_row + j);
+            next_row += pend_n;
+            pend_n = 0;
+        }
         while (next_row < target) {
             uint32_t nb = target - next_row;
             uint4 v0 = fetch(next_row), v1, v2, v3;

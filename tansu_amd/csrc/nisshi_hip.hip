@@ -286,10 +286,10 @@ constexpr uint32_t kHdrRunMax = 4096;
 __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
                                            const Work &w, uint64_t hdr_cap, BatchStream &stream,
                                            bool streaming, int lane) {
-    uint32_t count = c.record_count[b];
-    uint32_t rbase = c.rec_base[b];
-    uint64_t data_off = c.data_off[b];
-    Reader rd(blob + data_off, c.data_len[b]);
+    uint32_t count = uni(c.record_count[b]);
+    uint32_t rbase = uni(c.rec_base[b]);
+    uint64_t data_off = uni64(c.data_off[b]);
+    Reader rd(blob + data_off, uni(c.data_len[b]));
     if (streaming) {
         rd.ring = stream.ring;
         rd.ring_bias = (uint32_t)(data_off - stream.grid);
@@ -304,7 +304,8 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
     constexpr uint32_t kReach = kRingBytes - 2 * kRowBytes;
     for (uint32_t k = 0; k < count;) {
         uint32_t m = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
-        uint32_t found = 0, my_start = 0, my_size = 0;
+        uint32_t found = 0, my_start = 0, my_size = 0, my_used = 0;
+        int32_t my_len = 0;
         uint32_t round_start = pos;
         while (found < m) {
             uint32_t lanes = m - found;
@@ -320,12 +321,14 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
                 rd.wbase = -1000;
             }
             uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
-            uint32_t guess = guess64 < rd.len ? (uint32_t)guess64 : rd.len;
-            uint32_t p = guess;
+            bool in = (uint32_t)lane < lanes && guess64 < rd.len;
+            uint32_t guess = in ? (uint32_t)guess64 : 0;
             int32_t len = 0;
-            int st = (uint32_t)lane < lanes ? rd.varint(p, len) : NISSHI_TRY_GET;
-            bool ok = st == NISSHI_OK && len >= 0 && (uint32_t)len <= rd.len - p;
-            uint32_t size = ok ? p - guess + (uint32_t)len : 0;
+            uint32_t used = 0;
+            bool ok = in && fast_varint(rd.get64(guess), used, len);
+            // the whole record lies inside the data (this also catches a varint cut short)
+            ok = ok && len >= 0 && (uint64_t)guess + used + (uint32_t)len <= rd.len;
+            uint32_t size = ok ? used + (uint32_t)len : 0;
             uint64_t okmask = __ballot(ok);
             if (!(okmask & 1)) return false;
             uint64_t same = __ballot(ok && size == S);
@@ -333,35 +336,93 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
             uint32_t v = good;  // lanes below `good` are records of size S
             if (good < 64 && ((okmask >> good) & 1)) v = good + 1;
             if (v > lanes) v = lanes;
-            int src = lane - (int)found;
-            uint32_t s_start = __shfl(guess, src & 63, 64);
-            uint32_t s_size = __shfl(size, src & 63, 64);
-            if (src >= 0 && (uint32_t)src < v) {
-                my_start = s_start;
-                my_size = s_size;
+            v = uni(v);
+            if (found == 0) {  // the usual case: the records stay in the lanes that found them
+                if ((uint32_t)lane < v) {
+                    my_start = guess;
+                    my_size = size;
+                    my_used = used;
+                    my_len = len;
+                }
+            } else {
+                int src = (lane - (int)found) & 63;
+                uint32_t s_start = __shfl(guess, src, 64);
+                uint32_t s_size = __shfl(size, src, 64);
+                uint32_t s_used = __shfl(used, src, 64);
+                int32_t s_len = __shfl(len, src, 64);
+                if ((uint32_t)lane >= found && (uint32_t)lane < found + v) {
+                    my_start = s_start;
+                    my_size = s_size;
+                    my_used = s_used;
+                    my_len = s_len;
+                }
             }
-            S = __shfl(size, (int)v - 1, 64);
-            pos = __shfl(guess, (int)v - 1, 64) + S;
+            S = (uint32_t)__builtin_amdgcn_readlane((int)size, (int)v - 1);
+            pos = (uint32_t)__builtin_amdgcn_readlane((int)guess, (int)v - 1) + S;
             found += v;
         }
         m = found;
-        // ---- one lane per record
+        // start fetching what the next round will parse while this one is decoded
+        if (streaming) {
+            uint32_t next = count - k - m < (uint32_t)kWave ? count - k - m : (uint32_t)kWave;
+            if ((uint64_t)next * S > kReach) next = S ? kReach / S : 1;
+            if (next) stream.prefetch(stream.row_after(data_off + pos + (uint64_t)next * S + 64));
+        }
+        // ---- one lane per record: the fields after the length
         RecordFields f;
         bool live = (uint32_t)lane < m;
-        bool bad = false;
-        uint32_t p = my_start;
-        if (live) bad = read_record_head(rd, p, f) != NISSHI_OK;
-        uint32_t hc = live && !bad ? (uint32_t)f.hdr_count : 0;
-        uint32_t inc = wave_inclusive_scan(hc, lane);
-        uint32_t total = __shfl(inc, 63, 64);
+        uint32_t end = my_start + my_size;
+        uint32_t p = my_start + my_used;
+        bool ok = live;
+        f.length = my_len;
+        f.attributes = 0;
+        f.timestamp_delta = 0;
+        f.offset_delta = 0;
+        f.key_off = f.val_off = 0;
+        f.key_len = f.val_len = -1;
+        f.hdr_count = 0;
+        if (live) {
+            uint32_t used;
+            uint64_t w0 = rd.get64(p);  // attributes, then the timestamp delta
+            f.attributes = (uint32_t)w0 & 0xffu;
+            if (fast_varlong((uint32_t)(w0 >> 8), used, f.timestamp_delta)) {
+                p += 1 + used;
+            } else {
+                p += 1;
+                ok = rd.varlong(p, f.timestamp_delta) == NISSHI_OK;
+            }
+            ok = fast_varint(rd.get64(p), used, f.offset_delta) && ok;
+            p += used;
+            ok = fast_varint(rd.get64(p), used, f.key_len) && ok;
+            p += used;
+            f.key_off = p;
+            ok = ok && f.key_len >= -1 && p <= end && (uint32_t)(f.key_len < 0 ? 0 : f.key_len) <= end - p;
+            p += ok && f.key_len > 0 ? (uint32_t)f.key_len : 0u;
+            ok = fast_varint(rd.get64(p), used, f.val_len) && ok;
+            p += used;
+            f.val_off = p;
+            ok = ok && f.val_len >= -1 && p <= end && (uint32_t)(f.val_len < 0 ? 0 : f.val_len) <= end - p;
+            p += ok && f.val_len > 0 ? (uint32_t)f.val_len : 0u;
+            ok = fast_varint(rd.get64(p), used, f.hdr_count) && ok;
+            p += used;
+            // a header is at least two bytes: a count the record cannot hold is an error
+            ok = ok && f.hdr_count >= 0 && p <= end && (uint32_t)f.hdr_count <= (end - p) / 2;
+        }
+        uint32_t hc = ok ? (uint32_t)f.hdr_count : 0;
         uint64_t slot = 0;
-        if (total) {
+        uint32_t total = 0;
+        if (__any(hc != 0)) {
+            // equal header counts in every record (the usual case) need no scan
+            uint32_t hc0 = uni(hc);
+            uint32_t inc = __all(hc == (live ? hc0 : 0u)) ? (live ? ((uint32_t)lane + 1) * hc0 : m * hc0)
+                                                           : wave_inclusive_scan(hc, lane);
+            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             // records whose headers fit in the run in hand use it, the rest a new run
             uint64_t room = run_end - run_pos;
             bool fits = inc <= room;
             uint64_t fit_mask = __ballot(fits);
             uint32_t n_fit = fit_mask == ~0ull ? 64 : (uint32_t)__ffsll((long long)~fit_mask) - 1;
-            uint32_t used_old = n_fit ? __shfl(inc, (int)n_fit - 1, 64) : 0;
+            uint32_t used_old = n_fit ? (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)n_fit - 1) : 0;
             uint32_t rest = total - used_old;
             uint64_t new_base = 0;
             uint32_t grab = 0;
@@ -370,7 +431,7 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
                 uint64_t ahead = (uint64_t)total * (count - k - m) / m;
                 grab = rest + (uint32_t)(ahead < kHdrRunMax ? ahead : kHdrRunMax);
                 if (lane == 0) new_base = atomicAdd(hdr_cursor, (unsigned long long)grab);
-                new_base = __shfl(new_base, 0, 64);
+                new_base = uni64(new_base);
                 if (new_base + grab > hdr_cap) {
                     if (lane == 0) c.status[b] = NISSHI_CAPACITY;
                     return true;
@@ -383,21 +444,32 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
             } else {
                 run_pos += total;
             }
-            if (hdr_total == 0) first_slot = (uint32_t)__shfl(slot, __ffsll((long long)__ballot(hc > 0)) - 1, 64);
+            if (hdr_total == 0)
+                first_slot = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)slot, __ffsll((long long)__ballot(hc > 0)) - 1);
             hdr_total += total;
-        }
-        for (uint32_t j = 0; j < hc && !bad; j++) {
-            uint32_t ko, vo;
-            int32_t kl, vl;
-            bad = rd.octets(p, ko, kl) != NISSHI_OK || rd.octets(p, vo, vl) != NISSHI_OK;
-            if (!bad) {
-                c.hkey_off[slot + j] = ko;
-                c.hkey_len[slot + j] = kl;
-                c.hval_off[slot + j] = vo;
-                c.hval_len[slot + j] = vl;
+            for (uint32_t j = 0; j < hc && ok; j++) {
+                uint32_t used, ko, vo;
+                int32_t kl, vl;
+                ok = fast_varint(rd.get64(p), used, kl);
+                p += used;
+                ko = p;
+                ok = ok && kl >= -1 && p <= end && (uint32_t)(kl < 0 ? 0 : kl) <= end - p;
+                p += ok && kl > 0 ? (uint32_t)kl : 0u;
+                ok = fast_varint(rd.get64(p), used, vl) && ok;
+                p += used;
+                vo = p;
+                ok = ok && vl >= -1 && p <= end && (uint32_t)(vl < 0 ? 0 : vl) <= end - p;
+                p += ok && vl > 0 ? (uint32_t)vl : 0u;
+                if (ok) {
+                    c.hkey_off[slot + j] = ko;
+                    c.hkey_len[slot + j] = kl;
+                    c.hval_off[slot + j] = vo;
+                    c.hval_len[slot + j] = vl;
+                }
             }
         }
-        if (live && !bad) bad = p != my_start + my_size;
+        // the fields must end exactly where the length said
+        bool bad = live && (!ok || p != end);
         if (__any(bad)) return false;
         if (live) store_record(c, rbase + k + lane, f, (uint32_t)slot);
         k += m;
@@ -419,21 +491,22 @@ constexpr uint32_t kBigChunks = 8;
 __global__ __launch_bounds__(64) void decode_fused_kernel(const uint8_t *blob,
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
-                                                          uint64_t hdr_cap, const CrcTables *t) {
+                                                          uint64_t hdr_cap, const CrcTables *t, int dbg) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[kRingWords];
     uint32_t b = blockIdx.x;
     int lane = threadIdx.x;
     if (b >= n) return;
-    uint32_t chunks = w.n_chunks[b];
+    uint32_t chunks = uni(w.n_chunks[b]);
     bool do_crc = chunks >= 1 && chunks < kBigChunks;
-    bool do_walk = c.status[b] == NISSHI_OK && !(w.flags[b] & kFlagExact);
+    bool do_walk = uni(c.status[b]) == NISSHI_OK && !(uni(w.flags[b]) & kFlagExact) && !(dbg & 1);
     if (do_walk && (uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
         if (lane == 0) c.status[b] = NISSHI_CAPACITY;
         do_walk = false;
     }
     BatchStream stream;
+    stream.dbg = dbg;
     uint64_t lo = batch_off[b] + 21;
-    stream.init(blob, lo, do_crc ? lo + (uint64_t)c.batch_length[b] - 9 : lo, ring, lane);
+    stream.init(blob, lo, do_crc ? lo + (uint64_t)uni(c.batch_length[b]) - 9 : lo, (lds_u32 *)ring, lane);
     if (do_walk && !walk_batch(blob, b, c, w, hdr_cap, stream, do_crc, lane)) {
         if (lane == 0) w.flags[b] |= kFlagExact;
     }

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gf2_crc32c.h"
 #include "nisshi_hip.h"
 
 namespace nisshi {
@@ -54,6 +55,36 @@ __device__ __forceinline__ int varint32(uint64_t w, uint32_t avail, uint32_t &us
     return avail <= 5 ? NISSHI_TRY_GET : NISSHI_OVERFLOW;
 }
 
+// Branch-free form of VarInt::decode for the common case: a terminating byte
+// within the first five.  Returns false otherwise (a sixth byte, or a buffer
+// that ends inside the varint, which the caller detects through its own bounds);
+// the caller then leaves the batch to the sequential walk, which reproduces the
+// reference's outcome exactly.  As in the reference, the fifth byte's bits above
+// bit 31 are dropped.
+__device__ __forceinline__ bool fast_varint(uint64_t w, uint32_t &used, int32_t &out) {
+    uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    uint32_t stop = ~lo & 0x80808080u;  // bit 7 of every byte that ends a varint
+    uint32_t idx = stop ? (uint32_t)__builtin_ctz(stop) >> 3 : 4u;
+    uint32_t v = (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) | ((lo >> 2) & 0x1fc000u) |
+                 ((lo >> 3) & 0xfe00000u) | (hi << 28);
+    v &= idx == 4 ? 0xffffffffu : 0xffffffffu >> (25 - 7 * idx);
+    used = idx + 1;
+    out = (int32_t)(v >> 1) ^ -(int32_t)(v & 1u);
+    return stop != 0 || !(hi & 0x80u);
+}
+
+// The same for LongVarInt::decode when it ends within four bytes (|value| < 2^27).
+__device__ __forceinline__ bool fast_varlong(uint32_t lo, uint32_t &used, int64_t &out) {
+    uint32_t stop = ~lo & 0x80808080u;
+    uint32_t idx = (uint32_t)__builtin_ctz(stop | 0x80000000u) >> 3;
+    uint32_t v = (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) | ((lo >> 2) & 0x1fc000u) |
+                 ((lo >> 3) & 0xfe00000u);
+    v &= 0xffffffffu >> (25 - 7 * idx);
+    used = idx + 1;
+    out = (int64_t)((int32_t)(v >> 1) ^ -(int32_t)(v & 1u));
+    return stop != 0;
+}
+
 // A 20-byte window over the record data held in registers, so that the fields
 // of a record that sit next to each other cost one round trip to memory instead
 // of one each.  The window is five aligned dwords; loads never touch a dword
@@ -68,7 +99,7 @@ struct Reader {
     uint32_t len;
     int32_t wbase;  // position of the window's first byte (may be up to 3 below a valid position)
     uint32_t d0, d1, d2, d3, d4;
-    const uint32_t *ring;
+    const lds_u32 *ring;
     uint32_t ring_bias, ring_mask;
     uint32_t win_lo, win_hi;
 
@@ -80,7 +111,7 @@ struct Reader {
         if (pos >= win_lo && pos + 20 <= win_hi) {
             uint32_t o = pos + ring_bias;
             wbase = (int32_t)pos - (int32_t)(o & 3);
-            const uint32_t *q = ring + ((o & ring_mask) >> 2);
+            const lds_u32 *q = ring + ((o & ring_mask) >> 2);
             d0 = q[0];
             d1 = q[1];
             d2 = q[2];
@@ -93,23 +124,24 @@ struct Reader {
         uintptr_t a = p & ~uintptr_t(3);
         wbase = (int32_t)pos - (int32_t)(p & 3);
         a = a <= last ? a : last;
-        d0 = *reinterpret_cast<const uint32_t *>(a);
-        d1 = *reinterpret_cast<const uint32_t *>(a + 4 <= last ? a + 4 : last);
-        d2 = *reinterpret_cast<const uint32_t *>(a + 8 <= last ? a + 8 : last);
-        d3 = *reinterpret_cast<const uint32_t *>(a + 12 <= last ? a + 12 : last);
-        d4 = *reinterpret_cast<const uint32_t *>(a + 16 <= last ? a + 16 : last);
+        typedef __attribute__((address_space(1))) const uint32_t gbl_u32;  // global, not flat
+        d0 = *(gbl_u32 *)a;
+        d1 = *(gbl_u32 *)(a + 4 <= last ? a + 4 : last);
+        d2 = *(gbl_u32 *)(a + 8 <= last ? a + 8 : last);
+        d3 = *(gbl_u32 *)(a + 12 <= last ? a + 12 : last);
+        d4 = *(gbl_u32 *)(a + 16 <= last ? a + 16 : last);
     }
 
     // eight bytes starting at pos (pos < len)
     __device__ __forceinline__ uint64_t get64(uint32_t pos) {
-        int32_t o = (int32_t)pos - wbase;
-        if (o < 0 || o > 11) {
+        uint32_t o = pos - (uint32_t)wbase;
+        if (o > 11u) {  // also true when pos is below the window
             fill(pos);
-            o = (int32_t)pos - wbase;
+            o = pos - (uint32_t)wbase;
         }
         // shift every adjacent pair, then pick by dword offset: selecting among
         // computed values keeps the window in registers
-        uint32_t q = (uint32_t)o >> 2, r = (uint32_t)o & 3;
+        uint32_t q = o >> 2, r = o & 3;
         uint32_t a01 = __builtin_amdgcn_alignbyte(d1, d0, r);
         uint32_t a12 = __builtin_amdgcn_alignbyte(d2, d1, r);
         uint32_t a23 = __builtin_amdgcn_alignbyte(d3, d2, r);
