@@ -112,6 +112,15 @@ __device__ __forceinline__ uint32_t fsh(uint32_t hi, uint32_t lo, int r) {
     return __builtin_amdgcn_alignbit(hi, lo, r);  // ({hi,lo} >> r)[31:0]
 }
 
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // v_bitop3_b32, truth table of a ^ b ^ c
+}
+
+// The value of the next lane up, zero in lane 63 (v_mov_b32_dpp wave_shl:1, bound_ctrl:0).
+__device__ __forceinline__ uint32_t lane_above(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+
 // One fold: acc = next ^ (acc * x^8192 mod Q), Q = x^8192 + T.  The row is a
 // little-endian 8192-bit number spread over the wave; multiplying by x^t is a
 // right shift of the whole row by t bits.  The t low bits that fall off the
@@ -123,23 +132,26 @@ __device__ __forceinline__ void crc_fold_row(uint32_t (&a)[4], const uint32_t (&
                    (uint32_t)__builtin_amdgcn_readfirstlane(a[0]);
     uint64_t wrap = (low << 2) ^ (low << 5) ^ (low << 16) ^ (low << 21) ^ (low << 32) ^
                     (low << 37) ^ (low << 43) ^ (low << 59);  // 64 - t for every t > 0
-    uint32_t top = lane == 63 ? 0xFFFFFFFFu : 0u;
-    a[2] ^= (uint32_t)wrap & top;
-    a[3] ^= (uint32_t)(wrap >> 32) & top;
-    uint32_t n0 = __shfl_down(a[0], 1, 64);
-    uint32_t n1 = __shfl_down(a[1], 1, 64);
-    n0 &= ~top;  // nothing above lane 63
-    n1 &= ~top;
-    uint32_t w[6] = {a[0], a[1], a[2], a[3], n0, n1};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        uint32_t s = nx[i] ^ w[i] ^ w[i + 1];                 // x^0 and x^32
-        s ^= fsh(w[i + 1], w[i], 5) ^ fsh(w[i + 1], w[i], 21);
-        s ^= fsh(w[i + 1], w[i], 27) ^ fsh(w[i + 2], w[i + 1], 11);  // x^27, x^43
-        s ^= fsh(w[i + 2], w[i + 1], 16) ^ fsh(w[i + 2], w[i + 1], 27);  // x^48, x^59
-        s ^= fsh(w[i + 2], w[i + 1], 30);                     // x^62
-        a[i] = s;
-    }
+    bool top = lane == 63;
+    uint32_t w0 = a[0], w1 = a[1];
+    uint32_t w2 = a[2] ^ (top ? (uint32_t)wrap : 0u);
+    uint32_t w3 = a[3] ^ (top ? (uint32_t)(wrap >> 32) : 0u);
+    uint32_t w4 = lane_above(w0), w5 = lane_above(w1);
+    // shifted copies of each adjacent pair; the x^27 and x^59 terms share theirs
+    uint32_t p0_5 = fsh(w1, w0, 5), p0_21 = fsh(w1, w0, 21), p0_27 = fsh(w1, w0, 27);
+    uint32_t p1_5 = fsh(w2, w1, 5), p1_21 = fsh(w2, w1, 21), p1_27 = fsh(w2, w1, 27);
+    uint32_t p1_11 = fsh(w2, w1, 11), p1_16 = fsh(w2, w1, 16), p1_30 = fsh(w2, w1, 30);
+    uint32_t p2_5 = fsh(w3, w2, 5), p2_21 = fsh(w3, w2, 21), p2_27 = fsh(w3, w2, 27);
+    uint32_t p2_11 = fsh(w3, w2, 11), p2_16 = fsh(w3, w2, 16), p2_30 = fsh(w3, w2, 30);
+    uint32_t p3_5 = fsh(w4, w3, 5), p3_21 = fsh(w4, w3, 21), p3_27 = fsh(w4, w3, 27);
+    uint32_t p3_11 = fsh(w4, w3, 11), p3_16 = fsh(w4, w3, 16), p3_30 = fsh(w4, w3, 30);
+    uint32_t p4_11 = fsh(w5, w4, 11), p4_16 = fsh(w5, w4, 16), p4_27 = fsh(w5, w4, 27);
+    uint32_t p4_30 = fsh(w5, w4, 30);
+    // word i: x^0 w[i], x^32 w[i+1], x^5 x^21 x^27 of pair i, x^43 x^48 x^59 x^62 of pair i+1
+    a[0] = xor3(xor3(nx[0], w0, w1), xor3(p0_5, p0_21, p0_27), xor3(p1_11, p1_16, p1_27)) ^ p1_30;
+    a[1] = xor3(xor3(nx[1], w1, w2), xor3(p1_5, p1_21, p1_27), xor3(p2_11, p2_16, p2_27)) ^ p2_30;
+    a[2] = xor3(xor3(nx[2], w2, w3), xor3(p2_5, p2_21, p2_27), xor3(p3_11, p3_16, p3_27)) ^ p3_30;
+    a[3] = xor3(xor3(nx[3], w3, w4), xor3(p3_5, p3_21, p3_27), xor3(p4_11, p4_16, p4_27)) ^ p4_30;
 }
 
 __device__ __forceinline__ uint32_t wave_xor(uint32_t v) {

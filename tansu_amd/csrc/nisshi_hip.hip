@@ -318,7 +318,6 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
                 uint64_t from = stream.staged_from(), to = stream.staged_to();
                 rd.win_lo = from > data_off ? (uint32_t)(from - data_off) : 0;
                 rd.win_hi = to > data_off ? (uint32_t)(to - data_off) : 0;
-                rd.wbase = -1000;
             }
             uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
             bool in = (uint32_t)lane < lanes && guess64 < rd.len;
@@ -370,7 +369,7 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
         }
         // ---- one lane per record: the fields after the length
         RecordFields f;
-        bool live = (uint32_t)lane < m;
+        bool live = (uint32_t)lane < m && !(stream.dbg & 4);
         uint32_t end = my_start + my_size;
         uint32_t p = my_start + my_used;
         bool ok = live;
@@ -408,8 +407,8 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
             // a header is at least two bytes: a count the record cannot hold is an error
             ok = ok && f.hdr_count >= 0 && p <= end && (uint32_t)f.hdr_count <= (end - p) / 2;
         }
-        uint32_t hc = ok ? (uint32_t)f.hdr_count : 0;
-        uint64_t slot = 0;
+        uint32_t hc = ok && !(stream.dbg & 8) ? (uint32_t)f.hdr_count : 0;
+        uint32_t slot = 0;
         uint32_t total = 0;
         if (__any(hc != 0)) {
             // equal header counts in every record (the usual case) need no scan
@@ -437,7 +436,7 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
                     return true;
                 }
             }
-            slot = fits ? run_pos + (inc - hc) : new_base + (inc - hc - used_old);
+            slot = (uint32_t)(fits ? run_pos + (inc - hc) : new_base + (inc - hc - used_old));
             if (rest) {
                 run_pos = new_base + rest;
                 run_end = new_base + grab;
@@ -445,7 +444,7 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
                 run_pos += total;
             }
             if (hdr_total == 0)
-                first_slot = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)slot, __ffsll((long long)__ballot(hc > 0)) - 1);
+                first_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, __ffsll((long long)__ballot(hc > 0)) - 1);
             hdr_total += total;
             for (uint32_t j = 0; j < hc && ok; j++) {
                 uint32_t used, ko, vo;
@@ -469,9 +468,9 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
             }
         }
         // the fields must end exactly where the length said
-        bool bad = live && (!ok || p != end);
+        bool bad = live && (!ok || p != end) && !(stream.dbg & 8);
         if (__any(bad)) return false;
-        if (live) store_record(c, rbase + k + lane, f, (uint32_t)slot);
+        if (live) store_record(c, rbase + k + lane, f, slot);
         k += m;
         __syncthreads();  // every lane is done with the ring before it moves on
     }

@@ -26,9 +26,10 @@ __device__ __forceinline__ uint64_t window64(const uint8_t *data, uint32_t pos, 
     a0 = a0 <= last ? a0 : last;
     uintptr_t a1 = a0 + 4 <= last ? a0 + 4 : last;
     uintptr_t a2 = a0 + 8 <= last ? a0 + 8 : last;
-    uint32_t d0 = *reinterpret_cast<const uint32_t *>(a0);
-    uint32_t d1 = *reinterpret_cast<const uint32_t *>(a1);
-    uint32_t d2 = *reinterpret_cast<const uint32_t *>(a2);
+    typedef __attribute__((address_space(1))) const uint32_t gbl_u32;  // global, not flat
+    uint32_t d0 = *(gbl_u32 *)a0;
+    uint32_t d1 = *(gbl_u32 *)a1;
+    uint32_t d2 = *(gbl_u32 *)a2;
     uint32_t sh = (uint32_t)(p & 3);
     uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
@@ -85,70 +86,32 @@ __device__ __forceinline__ bool fast_varlong(uint32_t lo, uint32_t &used, int64_
     return stop != 0;
 }
 
-// A 20-byte window over the record data held in registers, so that the fields
-// of a record that sit next to each other cost one round trip to memory instead
-// of one each.  The window is five aligned dwords; loads never touch a dword
-// that holds no byte of the data (see window64).
+// Reads eight bytes at any byte position of a batch's record data.
 //
-// When the wave has staged a stretch of the batch in LDS (BatchStream), windows
-// inside [win_lo, win_hi) are read from there; anything else comes from global
-// memory.  `ring_bias` is the distance of the record data from the ring's grid
-// origin, which is 16-byte aligned like the blob, so byte alignment agrees.
+// When the wave has staged a stretch of the batch in LDS (BatchStream), positions
+// inside [win_lo, win_hi) are read from there with one unaligned ds_read_b64 (the
+// ring has a guard, so a read may run past its end); anything else comes from
+// global memory through aligned dword loads.  `ring_bias` is the distance of the
+// record data from the ring's grid origin.
 struct Reader {
     const uint8_t *data;
     uint32_t len;
-    int32_t wbase;  // position of the window's first byte (may be up to 3 below a valid position)
-    uint32_t d0, d1, d2, d3, d4;
     const lds_u32 *ring;
     uint32_t ring_bias, ring_mask;
     uint32_t win_lo, win_hi;
 
     __device__ __forceinline__ Reader(const uint8_t *data_, uint32_t len_)
-        : data(data_), len(len_), wbase(-1000), d0(0), d1(0), d2(0), d3(0), d4(0), ring(nullptr),
-          ring_bias(0), ring_mask(0), win_lo(0), win_hi(0) {}
-
-    __device__ __forceinline__ void fill(uint32_t pos) {
-        if (pos >= win_lo && pos + 20 <= win_hi) {
-            uint32_t o = pos + ring_bias;
-            wbase = (int32_t)pos - (int32_t)(o & 3);
-            const lds_u32 *q = ring + ((o & ring_mask) >> 2);
-            d0 = q[0];
-            d1 = q[1];
-            d2 = q[2];
-            d3 = q[3];
-            d4 = q[4];
-            return;
-        }
-        uintptr_t p = reinterpret_cast<uintptr_t>(data) + pos;
-        uintptr_t last = (reinterpret_cast<uintptr_t>(data) + len - 1) & ~uintptr_t(3);
-        uintptr_t a = p & ~uintptr_t(3);
-        wbase = (int32_t)pos - (int32_t)(p & 3);
-        a = a <= last ? a : last;
-        typedef __attribute__((address_space(1))) const uint32_t gbl_u32;  // global, not flat
-        d0 = *(gbl_u32 *)a;
-        d1 = *(gbl_u32 *)(a + 4 <= last ? a + 4 : last);
-        d2 = *(gbl_u32 *)(a + 8 <= last ? a + 8 : last);
-        d3 = *(gbl_u32 *)(a + 12 <= last ? a + 12 : last);
-        d4 = *(gbl_u32 *)(a + 16 <= last ? a + 16 : last);
-    }
+        : data(data_), len(len_), ring(nullptr), ring_bias(0), ring_mask(0), win_lo(0), win_hi(0) {}
 
     // eight bytes starting at pos (pos < len)
-    __device__ __forceinline__ uint64_t get64(uint32_t pos) {
-        uint32_t o = pos - (uint32_t)wbase;
-        if (o > 11u) {  // also true when pos is below the window
-            fill(pos);
-            o = pos - (uint32_t)wbase;
+    __device__ __forceinline__ uint64_t get64(uint32_t pos) const {
+        if (pos >= win_lo && pos + 8 <= win_hi) {
+            typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+            typedef __attribute__((address_space(3))) const u64_unaligned lds_u64;
+            typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+            return *(lds_u64 *)((lds_u8 *)ring + ((pos + ring_bias) & ring_mask));
         }
-        // shift every adjacent pair, then pick by dword offset: selecting among
-        // computed values keeps the window in registers
-        uint32_t q = o >> 2, r = o & 3;
-        uint32_t a01 = __builtin_amdgcn_alignbyte(d1, d0, r);
-        uint32_t a12 = __builtin_amdgcn_alignbyte(d2, d1, r);
-        uint32_t a23 = __builtin_amdgcn_alignbyte(d3, d2, r);
-        uint32_t a34 = __builtin_amdgcn_alignbyte(d4, d3, r);
-        uint32_t lo = q == 0 ? a01 : q == 1 ? a12 : a23;
-        uint32_t hi = q == 0 ? a12 : q == 1 ? a23 : a34;
-        return ((uint64_t)hi << 32) | lo;
+        return window64(data, pos, len);
     }
 
     __device__ __forceinline__ int varint(uint32_t &pos, int32_t &out) {
