@@ -218,14 +218,17 @@ __device__ inline uint32_t crc_rows(const uint8_t *base, uint64_t grid, uint64_t
 
 
 // A wave's pass over one batch: rows are fetched in order with coalesced 16-byte
-// loads, a few in flight at a time, folded into the CRC accumulator and copied
-// raw into a ring of the last kRingRows rows in LDS, from which the same wave
-// then parses records.  The batch is read from HBM once.
+// loads, folded into the CRC accumulator and copied raw into a ring of the last
+// kRingRows rows in LDS, from which the same wave then parses records.  The
+// batch is read from HBM once.  The caller loads the rows it will need next into
+// registers (load), works on what is in the ring while they arrive, and then
+// moves them in (take_loaded): both within one pass of its loop, so that no load
+// is in flight across a loop edge.
 constexpr int kRingRows = 8;
 constexpr int kRingBytes = kRingRows * kRowBytes;
 constexpr int kRingGuard = 64;  // the ring's first bytes again, so a window may run past the end
 constexpr int kRingWords = (kRingBytes + kRingGuard) / 4;
-constexpr int kPrefetchRows = 8;
+constexpr int kAhead = 8;
 // pointers into LDS keep their address space, so that accesses are ds_read /
 // ds_write and not flat instructions
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -239,10 +242,7 @@ struct BatchStream {
     uint32_t acc[4];
     lds_u32 *ring;
     int lane;
-    int dbg;
-    // rows fetched ahead of time and not yet folded or staged (see prefetch)
-    uint4 pend[kPrefetchRows];
-    uint32_t pend_n;
+    const uint8_t *lane_ptr;  // this lane's 16 bytes of row 0
 
     __device__ __forceinline__ void init(const uint8_t *base_, uint64_t lo_, uint64_t hi_,
                                          lds_u32 *ring_, int lane_) {
@@ -252,9 +252,9 @@ struct BatchStream {
         grid = lo & ~uint64_t(15);
         rows = (uint32_t)((hi - grid + kRowBytes - 1) / kRowBytes);
         next_row = 0;
-        pend_n = 0;
         ring = ring_;
         lane = lane_;
+        lane_ptr = base + grid + (uint64_t)lane * 16;
         acc[0] = acc[1] = acc[2] = acc[3] = 0;
     }
 
@@ -265,84 +265,90 @@ struct BatchStream {
         return r < rows ? (uint32_t)r : rows;
     }
 
-    __device__ __forceinline__ bool edge(uint32_t r) const { return r == 0 || r + 1 == rows; }
+    __device__ __forceinline__ bool edge(uint32_t r) const { return r == 0 || r + 1 >= rows; }
 
-    __device__ __forceinline__ uint4 fetch(uint32_t r) const {
-        uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
-        // rows between the first and the last lie wholly inside [lo, hi)
-        if (!edge(r)) return *reinterpret_cast<const uint4 *>(base + addr);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (addr + 16 > lo && addr < hi) v = *reinterpret_cast<const uint4 *>(base + addr);
-        return v;
+    // Where this lane reads its 16 bytes of row r.  Every lane loads, whatever its
+    // bytes hold: lanes of the last row that lie past the data (and rows past the
+    // last) re-read the last 16 data bytes instead, and fix_edge() discards what
+    // they got.
+    __device__ __forceinline__ const uint8_t *row_ptr(uint32_t r) const {
+        const uint8_t *p = lane_ptr + (uint64_t)r * kRowBytes;
+        if (r + 1 >= rows) {
+            const uint8_t *last = base + ((hi - 1) & ~uint64_t(15));
+            p = p < last ? p : last;
+        }
+        return p;
     }
 
-    __device__ __forceinline__ void take(uint4 v, uint32_t r) {
-        // raw bytes into the ring (bytes outside [lo, hi) in the edge words are never parsed)
+    __device__ __forceinline__ u32x4 fetch(uint32_t r) const {
+        return *reinterpret_cast<const u32x4 *>(row_ptr(r));
+    }
+
+    // Row r into the ring (raw: bytes outside [lo, hi) are never parsed) and into
+    // the CRC.  The accumulator starts at zero, and folding zero gives zero.
+    __device__ __forceinline__ void take(u32x4 v, uint32_t r) {
         uint32_t slot = r & (kRingRows - 1);
-        u32x4 raw = {v.x, v.y, v.z, v.w};
-        *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4) = raw;
-        if (slot == 0 && lane < kRingGuard / 16) *(lds_u128 *)(ring + kRingBytes / 4 + lane * 4) = raw;
+        *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4) = v;
+        if (slot == 0 && lane < kRingGuard / 16) *(lds_u128 *)(ring + kRingBytes / 4 + lane * 4) = v;
         uint32_t nx[4] = {v.x, v.y, v.z, v.w};
-        if (edge(r)) {
-            uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
-            if (addr < lo || addr + 16 > hi) {
+        crc_fold_row(acc, nx, lane);
+    }
+
+    // The first and the last row were folded as loaded: take out the bytes that
+    // are not data, and complement the first four data bytes (the CRC's initial
+    // value 0xFFFFFFFF).  The fold is linear, so this is an XOR into the
+    // accumulator, before the next row is folded.
+    __device__ __forceinline__ void fix_edge(uint32_t r) {
+        uint32_t slot = r & (kRingRows - 1);
+        u32x4 raw = *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4);
+        uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
 #pragma unroll
-                for (int i = 0; i < 4; i++) nx[i] &= byte_mask(addr + 4 * i, lo, hi);
-            }
-            if (addr + 16 > lo && addr < lo + 4) {  // the 0xFFFFFFFF initial value
-#pragma unroll
-                for (int i = 0; i < 4; i++) nx[i] ^= byte_mask(addr + 4 * i, lo, lo + 4);
-            }
-        }
-        if (r == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = nx[i];
-        } else if (dbg & 2) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] ^= nx[i];
-        } else {
-            crc_fold_row(acc, nx, lane);
+        for (int i = 0; i < 4; i++) {
+            uint32_t fix = raw[i] & ~byte_mask(addr + 4 * i, lo, hi);
+            if (r == 0) fix ^= byte_mask(addr + 4 * i, lo, lo + 4);
+            acc[i] ^= fix;
         }
     }
 
-    // Issue the loads of the rows up to `target` (at most kPrefetchRows of them) and
-    // return at once: the data is folded and staged by the next advance, after the
-    // wave has spent the latency parsing what is already in the ring.
-    __device__ __forceinline__ void prefetch(uint32_t target) {
-        target = uni(target);
-        if (target > rows) target = rows;
-        if (pend_n || target <= next_row) return;
-        uint32_t n = target - next_row;
-        if (n > (uint32_t)kPrefetchRows) n = kPrefetchRows;
+    // Issue the loads of rows next_row .. next_row + n - 1 (n <= kAhead).  All the
+    // addresses are formed before the first load goes out: the compiler waits for
+    // every load it thinks outstanding before it lets address arithmetic reuse a
+    // register that a load fills, and between the loads that wait would be a real one.
+    __device__ __forceinline__ void load(u32x4 (&q)[kAhead], uint32_t n) const {
+        typedef __attribute__((address_space(1))) const u32x4 gbl_u128;  // global, not flat
+        gbl_u128 *p[kAhead];
 #pragma unroll
-        for (int j = 0; j < kPrefetchRows; j++)
-            if ((uint32_t)j < n) pend[j] = fetch(next_row + j);
-        pend_n = n;
+        for (int j = 0; j < kAhead; j++) p[j] = (gbl_u128 *)(uintptr_t)row_ptr(next_row + j);
+#pragma unroll
+        for (int j = 0; j < kAhead; j++) asm volatile("" : "+v"(p[j]));
+#pragma unroll
+        for (int j = 0; j < kAhead; j++)
+            if ((uint32_t)j < n) q[j] = *p[j];
     }
 
-    // consume rows up to (not including) `target`; rows already prefetched are
-    // consumed even when they lie beyond it
-    __device__ __forceinline__ void advance(uint32_t target) {
+    // Move the first n of the rows loaded into the ring and the CRC.
+    __device__ __forceinline__ void take_loaded(const u32x4 (&q)[kAhead], uint32_t n) {
+#pragma unroll
+        for (int j = 0; j < kAhead; j++) {
+            if ((uint32_t)j < n) {
+                take(q[j], next_row + j);
+                if (j == 0 && next_row == 0) fix_edge(0);
+            }
+        }
+        next_row += n;
+        if (n && next_row == rows && rows > 1) fix_edge(rows - 1);
+    }
+
+    // Rows up to (not including) `target`, one at a time: for the start of a batch
+    // and for what the walk did not ask for in advance.
+    __device__ __forceinline__ void pull(uint32_t target) {
         target = uni(target);
         if (target > rows) target = rows;
-        if (pend_n) {
-#pragma unroll
-            for (int j = 0; j < kPrefetchRows; j++)
-                if ((uint32_t)j < pend_n) take(pend[j], next_row + j);
-            next_row += pend_n;
-            pend_n = 0;
-        }
+#pragma nounroll
         while (next_row < target) {
-            uint32_t nb = target - next_row;
-            uint4 v0 = fetch(next_row), v1, v2, v3;
-            if (nb > 1) v1 = fetch(next_row + 1);
-            if (nb > 2) v2 = fetch(next_row + 2);
-            if (nb > 3) v3 = fetch(next_row + 3);
-            take(v0, next_row);
-            if (nb > 1) take(v1, next_row + 1);
-            if (nb > 2) take(v2, next_row + 2);
-            if (nb > 3) take(v3, next_row + 3);
-            next_row += nb < 4 ? nb : 4;
+            take(fetch(next_row), next_row);
+            if (edge(next_row)) fix_edge(next_row);
+            next_row++;
         }
     }
 
@@ -357,7 +363,7 @@ struct BatchStream {
 
     // the CRC-32C of [lo, hi)
     __device__ __forceinline__ uint32_t finish(const CrcTables *t) {
-        advance(rows);
+        pull(rows);
         if (hi == lo) return 0;
         uint32_t r = crc_row_residue(acc, lane, t);
         uint64_t pad = grid + (uint64_t)rows * kRowBytes - hi;

@@ -30,7 +30,8 @@ constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 // Internal per-batch flags
-constexpr uint32_t kFlagExact = 1u;  // needs the sequential walk
+constexpr uint32_t kFlagExact = 1u;   // needs the sequential walk
+constexpr uint32_t kFlagGlobal = 2u;  // needs the walk from global memory, from a resume point
 
 struct Work {
     uint32_t *alloc_count;  // record slots the batch gets
@@ -38,6 +39,8 @@ struct Work {
     uint32_t *chunk_base;   // exclusive scan of n_chunks, n + 1 entries
     uint32_t *partial;      // one residue per CRC work item
     uint32_t *flags;
+    uint32_t *resume_k;     // kFlagGlobal: the first record not yet decoded
+    uint32_t *resume_pos;   // and its offset in the record data
     uint64_t *totals;       // [0] record slots [1] header slots [2] failed [3] exact [4] out bytes [5] chunks
 };
 
@@ -240,18 +243,30 @@ __global__ void crc_finish_kernel(const uint64_t *batch_off, const int32_t *batc
 
 // ------------------------------------------------------------ record walk
 
-__device__ __forceinline__ void store_record(const nisshi_columns &c, uint32_t r,
+// A store into a column whose base is the same in every lane: the base stays in
+// scalar registers and the lane supplies a 32-bit byte offset, so the address
+// costs no vector arithmetic.
+template <class T>
+__device__ __forceinline__ void put(T *base, uint32_t byte_off, T v) {
+    *reinterpret_cast<T *>(reinterpret_cast<uint8_t *>(base) + byte_off) = v;
+}
+
+// The record at index r0 + lane; r0 is uniform.
+__device__ __forceinline__ void store_record(const nisshi_columns &c, uint64_t r0, uint32_t lane,
                                              const RecordFields &f, uint32_t hdr_slot) {
-    c.length[r] = f.length;
-    c.rattributes[r] = (uint8_t)f.attributes;
-    c.timestamp_delta[r] = f.timestamp_delta;
-    c.offset_delta[r] = f.offset_delta;
-    c.key_off[r] = f.key_off;
-    c.key_len[r] = f.key_len;
-    c.val_off[r] = f.val_off;
-    c.val_len[r] = f.val_len;
-    c.rhdr_base[r] = hdr_slot;
-    c.rhdr_count[r] = f.hdr_count;
+    // the lane's share of the addresses is cheap to form here; left visible, the
+    // compiler keeps one 64-bit pointer per column and lane alive across the walk
+    asm volatile("" : "+v"(lane));
+    put(c.length + r0, lane * 4, f.length);
+    put(c.rattributes + r0, lane, (uint8_t)f.attributes);
+    put(c.timestamp_delta + r0, lane * 8, f.timestamp_delta);
+    put(c.offset_delta + r0, lane * 4, f.offset_delta);
+    put(c.key_off + r0, lane * 4, f.key_off);
+    put(c.key_len + r0, lane * 4, f.key_len);
+    put(c.val_off + r0, lane * 4, f.val_off);
+    put(c.val_len + r0, lane * 4, f.val_len);
+    put(c.rhdr_base + r0, lane * 4, hdr_slot);
+    put(c.rhdr_count + r0, lane * 4, f.hdr_count);
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
@@ -263,62 +278,94 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
     return v;
 }
 
+// Keeps the compiler from moving LDS accesses across this point.  One wave's
+// LDS instructions execute in order, so a block of one wave needs no more.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 // Header slots are handed out from one cursor in runs, so that a batch's
 // headers sit in a few contiguous pieces and a record's headers are always
 // contiguous; the order of the pieces between batches is not defined.
 constexpr uint32_t kHdrRunMax = 4096;
 
-// The record walk of one batch by one wave.  Returns false when the batch has to
-// be walked sequentially (exact_kernel): a length that disagrees with the fields
-// it describes, or any decode error.
-//
-// Record starts are found up to 64 at a time by speculation: lane i assumes that
-// the i-th next record starts i * S bytes on, S being the size of the record
-// before, and decodes the length varint there.  Lanes up to and including the
-// first one whose size differs from S did start on a record, and the walk
-// resumes after that lane's record.  Batches of equal-sized records resolve 64
-// records per step, ragged ones at least one.  Each resolved record is then
-// decoded by its lane and must end where its length said.
-//
-// With `stream` the wave first pulls the rows it is about to parse through the
-// CRC and into its LDS ring, and the parse reads LDS; records that do not fit
-// the ring are read from global memory.
-__device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
-                                           const Work &w, uint64_t hdr_cap, BatchStream &stream,
-                                           bool streaming, int lane) {
-    uint32_t count = uni(c.record_count[b]);
-    uint32_t rbase = uni(c.rec_base[b]);
-    uint64_t data_off = uni64(c.data_off[b]);
-    Reader rd(blob + data_off, uni(c.data_len[b]));
-    if (streaming) {
-        rd.ring = stream.ring;
-        rd.ring_bias = (uint32_t)(data_off - stream.grid);
-        rd.ring_mask = kRingBytes - 1;
+struct HeaderRuns {
+    unsigned long long *cursor;
+    uint64_t cap;
+    uint64_t run_pos, run_end;  // slots in hand
+    uint32_t total, first_slot;  // of the batch so far
+
+    // Slots for one round of `m` records, `left` records of the batch following
+    // it; lane's record has hc headers (0 in lanes without a record).  Returns
+    // false when the header columns are full.  When the round's slots are one
+    // piece, `piece` is its first slot.
+    __device__ __forceinline__ bool take(uint32_t hc, uint32_t m, uint32_t left, int lane,
+                                         uint32_t &slot, uint64_t &piece, bool &one_piece) {
+        // equal header counts in every record (the usual case) need no scan
+        uint32_t hc0 = uni(hc);
+        bool live = (uint32_t)lane < m;
+        uint32_t inc = __all(hc == (live ? hc0 : 0u)) ? (live ? ((uint32_t)lane + 1) * hc0 : m * hc0)
+                                                       : wave_inclusive_scan(hc, lane);
+        uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        // records whose headers fit in the run in hand use it, the rest a new run
+        uint64_t room = run_end - run_pos;
+        bool fits = inc <= room;
+        uint64_t fit_mask = __ballot(fits);
+        uint32_t n_fit = fit_mask == ~0ull ? 64 : (uint32_t)__ffsll((long long)~fit_mask) - 1;
+        uint32_t used_old = n_fit ? (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)n_fit - 1) : 0;
+        uint32_t rest = sum - used_old;
+        uint64_t new_base = 0;
+        uint32_t grab = 0;
+        if (rest) {
+            // take enough for the records still to come at this round's density
+            uint64_t ahead = (uint64_t)sum * left / m;
+            grab = rest + (uint32_t)(ahead < kHdrRunMax ? ahead : kHdrRunMax);
+            if (lane == 0) new_base = atomicAdd(cursor, (unsigned long long)grab);
+            new_base = uni64(new_base);
+            if (new_base + grab > cap) return false;
+        }
+        one_piece = rest == 0 || used_old == 0;
+        piece = rest ? new_base : run_pos;
+        slot = (uint32_t)(fits ? run_pos : new_base) + inc - hc - (fits ? 0 : used_old);
+        if (rest) {
+            run_pos = new_base + rest;
+            run_end = new_base + grab;
+        } else {
+            run_pos += sum;
+        }
+        if (total == 0)
+            first_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, __ffsll((long long)__ballot(hc > 0)) - 1);
+        total += sum;
+        return true;
     }
-    unsigned long long *hdr_cursor = reinterpret_cast<unsigned long long *>(w.totals + 1);
-    uint64_t run_pos = 0, run_end = 0;  // header slots in hand
-    uint32_t hdr_total = 0, first_slot = 0;
-    uint32_t pos = 0;
-    uint32_t S = count ? rd.len / count : 0;
-    // with a ring, speculate only as far as the ring reaches
-    constexpr uint32_t kReach = kRingBytes - 2 * kRowBytes;
-    for (uint32_t k = 0; k < count;) {
+};
+
+// How a wave's walk of a batch ended.
+constexpr int kWalkDone = 0;
+constexpr int kWalkExact = 1;   // a record that does not decode, or whose length disagrees: exact_kernel
+constexpr int kWalkGlobal = 2;  // records the streamed walk cannot express: walk_global_kernel
+
+// ---- the walk from global memory
+//
+// One wave per batch.  Record starts are found up to 64 at a time by
+// speculation: lane i assumes that the i-th next record starts i * S bytes on, S
+// being the size of the record before, and decodes the length varint there.
+// Lanes up to and including the first one whose size differs from S did start on
+// a record, and the walk resumes after that lane's record.  Each resolved record
+// is then decoded by its lane and must end where its length said.  This is the
+// walk for batches the streamed walk leaves: records too large for its ring, or
+// of a shape it cannot express.  Starts at record k0, byte pos0 of the record data.
+__device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
+                                           HeaderRuns &runs, uint32_t k0, uint32_t pos0, int lane) {
+    uint32_t count = uni(c.record_count[b]);
+    uint64_t rbase = uni(c.rec_base[b]);
+    Reader rd(blob + uni64(c.data_off[b]), uni(c.data_len[b]));
+    uint32_t pos = pos0;
+    uint32_t S = count > k0 ? (rd.len - pos0) / (count - k0) : 0;
+    for (uint32_t k = k0; k < count;) {
         uint32_t m = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
         uint32_t found = 0, my_start = 0, my_size = 0, my_used = 0;
         int32_t my_len = 0;
-        uint32_t round_start = pos;
         while (found < m) {
             uint32_t lanes = m - found;
-            if (streaming) {
-                if ((uint64_t)lanes * S > kReach) lanes = S ? kReach / S : 1;
-                if (lanes == 0) lanes = 1;
-                if (pos + (uint64_t)lanes * S + 64 - round_start > kReach && found) break;
-                stream.advance(stream.row_after(data_off + pos + (uint64_t)lanes * S + 64));
-                __syncthreads();
-                uint64_t from = stream.staged_from(), to = stream.staged_to();
-                rd.win_lo = from > data_off ? (uint32_t)(from - data_off) : 0;
-                rd.win_hi = to > data_off ? (uint32_t)(to - data_off) : 0;
-            }
             uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
             bool in = (uint32_t)lane < lanes && guess64 < rd.len;
             uint32_t guess = in ? (uint32_t)guess64 : 0;
@@ -329,50 +376,34 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
             ok = ok && len >= 0 && (uint64_t)guess + used + (uint32_t)len <= rd.len;
             uint32_t size = ok ? used + (uint32_t)len : 0;
             uint64_t okmask = __ballot(ok);
-            if (!(okmask & 1)) return false;
+            if (!(okmask & 1)) return kWalkExact;
             uint64_t same = __ballot(ok && size == S);
             uint32_t good = ~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64;
             uint32_t v = good;  // lanes below `good` are records of size S
             if (good < 64 && ((okmask >> good) & 1)) v = good + 1;
             if (v > lanes) v = lanes;
             v = uni(v);
-            if (found == 0) {  // the usual case: the records stay in the lanes that found them
-                if ((uint32_t)lane < v) {
-                    my_start = guess;
-                    my_size = size;
-                    my_used = used;
-                    my_len = len;
-                }
-            } else {
-                int src = (lane - (int)found) & 63;
-                uint32_t s_start = __shfl(guess, src, 64);
-                uint32_t s_size = __shfl(size, src, 64);
-                uint32_t s_used = __shfl(used, src, 64);
-                int32_t s_len = __shfl(len, src, 64);
-                if ((uint32_t)lane >= found && (uint32_t)lane < found + v) {
-                    my_start = s_start;
-                    my_size = s_size;
-                    my_used = s_used;
-                    my_len = s_len;
-                }
+            int src = (lane - (int)found) & 63;
+            uint32_t s_start = __shfl(guess, src, 64);
+            uint32_t s_size = __shfl(size, src, 64);
+            uint32_t s_used = __shfl(used, src, 64);
+            int32_t s_len = __shfl(len, src, 64);
+            if ((uint32_t)lane >= found && (uint32_t)lane < found + v) {
+                my_start = s_start;
+                my_size = s_size;
+                my_used = s_used;
+                my_len = s_len;
             }
             S = (uint32_t)__builtin_amdgcn_readlane((int)size, (int)v - 1);
             pos = (uint32_t)__builtin_amdgcn_readlane((int)guess, (int)v - 1) + S;
             found += v;
         }
-        m = found;
-        // start fetching what the next round will parse while this one is decoded
-        if (streaming) {
-            uint32_t next = count - k - m < (uint32_t)kWave ? count - k - m : (uint32_t)kWave;
-            if ((uint64_t)next * S > kReach) next = S ? kReach / S : 1;
-            if (next) stream.prefetch(stream.row_after(data_off + pos + (uint64_t)next * S + 64));
-        }
         // ---- one lane per record: the fields after the length
-        RecordFields f;
-        bool live = (uint32_t)lane < m && !(stream.dbg & 4);
+        bool live = (uint32_t)lane < m;
         uint32_t end = my_start + my_size;
         uint32_t p = my_start + my_used;
         bool ok = live;
+        RecordFields f;
         f.length = my_len;
         f.attributes = 0;
         f.timestamp_delta = 0;
@@ -407,45 +438,15 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
             // a header is at least two bytes: a count the record cannot hold is an error
             ok = ok && f.hdr_count >= 0 && p <= end && (uint32_t)f.hdr_count <= (end - p) / 2;
         }
-        uint32_t hc = ok && !(stream.dbg & 8) ? (uint32_t)f.hdr_count : 0;
+        uint32_t hc = ok ? (uint32_t)f.hdr_count : 0;
         uint32_t slot = 0;
-        uint32_t total = 0;
         if (__any(hc != 0)) {
-            // equal header counts in every record (the usual case) need no scan
-            uint32_t hc0 = uni(hc);
-            uint32_t inc = __all(hc == (live ? hc0 : 0u)) ? (live ? ((uint32_t)lane + 1) * hc0 : m * hc0)
-                                                           : wave_inclusive_scan(hc, lane);
-            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            // records whose headers fit in the run in hand use it, the rest a new run
-            uint64_t room = run_end - run_pos;
-            bool fits = inc <= room;
-            uint64_t fit_mask = __ballot(fits);
-            uint32_t n_fit = fit_mask == ~0ull ? 64 : (uint32_t)__ffsll((long long)~fit_mask) - 1;
-            uint32_t used_old = n_fit ? (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)n_fit - 1) : 0;
-            uint32_t rest = total - used_old;
-            uint64_t new_base = 0;
-            uint32_t grab = 0;
-            if (rest) {
-                // take enough for the records still to come at this round's density
-                uint64_t ahead = (uint64_t)total * (count - k - m) / m;
-                grab = rest + (uint32_t)(ahead < kHdrRunMax ? ahead : kHdrRunMax);
-                if (lane == 0) new_base = atomicAdd(hdr_cursor, (unsigned long long)grab);
-                new_base = uni64(new_base);
-                if (new_base + grab > hdr_cap) {
-                    if (lane == 0) c.status[b] = NISSHI_CAPACITY;
-                    return true;
-                }
+            uint64_t piece;
+            bool one_piece;
+            if (!runs.take(hc, m, count - k - m, lane, slot, piece, one_piece)) {
+                if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+                return kWalkDone;
             }
-            slot = (uint32_t)(fits ? run_pos + (inc - hc) : new_base + (inc - hc - used_old));
-            if (rest) {
-                run_pos = new_base + rest;
-                run_end = new_base + grab;
-            } else {
-                run_pos += total;
-            }
-            if (hdr_total == 0)
-                first_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, __ffsll((long long)__ballot(hc > 0)) - 1);
-            hdr_total += total;
             for (uint32_t j = 0; j < hc && ok; j++) {
                 uint32_t used, ko, vo;
                 int32_t kl, vl;
@@ -468,50 +469,435 @@ __device__ __forceinline__ bool walk_batch(const uint8_t *blob, uint32_t b, cons
             }
         }
         // the fields must end exactly where the length said
-        bool bad = live && (!ok || p != end) && !(stream.dbg & 8);
-        if (__any(bad)) return false;
-        if (live) store_record(c, rbase + k + lane, f, slot);
+        if (__any(live && (!ok || p != end))) return kWalkExact;
+        if (live) store_record(c, rbase + k, (uint32_t)lane, f, slot);
         k += m;
-        __syncthreads();  // every lane is done with the ring before it moves on
     }
-    if (lane == 0) {
-        c.hdr_count[b] = hdr_total;
-        c.hdr_base[b] = first_slot;
+    return kWalkDone;
+}
+
+// ---- the streamed walk
+//
+// The shape of a record is everything in it but the payload bytes and the values
+// of attributes, timestamp_delta and offset_delta: the bytes of every length and
+// count varint and the widths of the two deltas.  Records produced by one client
+// mostly share a shape, and a record of a known shape needs no varint walk: its
+// fields sit at known offsets.  The wave learns the shape of a record as a list
+// of masked 32-bit compares (kept in LDS, as are the header spans relative to the
+// record start) and tests the records that follow against it, 64 at a time.
+constexpr uint32_t kShapeChecks = 24;  // even
+constexpr uint32_t kShapeHdrs = 16;
+constexpr uint32_t kShapeWords = (kShapeChecks + kShapeHdrs + 3) * 4;  // and the learnt scalars
+
+struct Shape {
+    uint32_t n_checks;  // 0: none learnt
+    uint32_t n_len;     // bytes of the length varint
+    int32_t length;     // its value
+    uint32_t o_od;      // offsets from the start of the record
+    uint32_t o_key, o_val;
+    int32_t klen, vlen;
+    uint32_t hc;
+};
+
+// Unaligned reads of the wave's LDS ring.  `at` is a position in the record data
+// plus the distance of the record data from the ring's origin.
+struct RingView {
+    const lds_u32 *ring;
+    __device__ __forceinline__ uint32_t read32(uint32_t at) const {
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+        typedef __attribute__((address_space(3))) const u32_unaligned lds_u32u;
+        typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+        return *(lds_u32u *)((lds_u8 *)ring + (at & (kRingBytes - 1)));
     }
-    return true;
+    __device__ __forceinline__ uint64_t read64(uint32_t at) const {
+        typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+        typedef __attribute__((address_space(3))) const u64_unaligned lds_u64;
+        typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+        return *(lds_u64 *)((lds_u8 *)ring + (at & (kRingBytes - 1)));
+    }
+};
+
+// Learn the shape of the record of `size` bytes at ring position `at0`:
+// Record::decode (record.rs:254-277) on that one record, by lane 0, which leaves
+// the compares, the header spans and the scalars of the shape in LDS.  The record's
+// length varint is known to be valid.  kWalkExact when the record does not decode
+// or does not end where its length says, kWalkGlobal when the compares cannot
+// express it (a varint of five bytes or more, too many fields).
+//
+// The fields are walked by one loop: 0 length, 1 timestamp delta (after the
+// attributes byte), 2 offset delta, 3 key, 4 value, 5 header count, then a key
+// and a value per header.  The bytes of every varint belong to the shape, except
+// that of the two deltas only the widths do.
+__device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView ring, uint32_t at0, uint32_t size) {
+    lds_u128 *htab = tab + kShapeChecks;
+    lds_u128 *out = htab + kShapeHdrs;
+    uint32_t p = 0;  // offset in the record
+    uint32_t cur_off = 0, cur_mask = 0, cur_pat = 0, noted = 0;
+    uint32_t fields = 6;
+    uint32_t n_len = 0, o_od = 0, o_key = 0, o_val = 0, hc = 0, ko = 0;
+    int32_t length = 0, klen = 0, vlen = 0, kl = 0;
+    bool wide = false, bad = false;
+    for (uint32_t i = 0; i < fields && !bad; i++) {
+        bool delta = i == 1 || i == 2;
+        if (i == 1) p += 1;
+        uint64_t w = ring.read64(at0 + p);
+        uint32_t used;
+        int32_t v;
+        bad = !fast_varint(w, used, v);
+        wide = wide || used > 4;
+        // into the compare in hand if it fits, else start the next
+        uint32_t bytes = used >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * used));
+        uint32_t mk = delta ? bytes & 0x80808080u : bytes;
+        if (p + used > cur_off + 4) {
+            if (noted < kShapeChecks) tab[noted] = u32x4{cur_off, cur_mask, cur_pat, 0};
+            noted++;
+            cur_off = p;
+            cur_mask = 0;
+            cur_pat = 0;
+        }
+        uint32_t sh = (p - cur_off) * 8;
+        cur_mask |= mk << sh;
+        cur_pat |= ((uint32_t)w & mk) << sh;
+        if (i == 2) o_od = p;
+        p += used;
+        if (i == 0) {
+            n_len = used;
+            length = v;
+        } else if (i == 5) {
+            // a header is at least two bytes: a count the record cannot hold is an error
+            bad = bad || v < 0 || p > size || (uint32_t)v > (size - p) / 2;
+            hc = bad ? 0 : (uint32_t)v;
+            fields = 6 + 2 * (hc <= kShapeHdrs ? hc : 0);
+        } else if (!delta) {
+            // Octets::decode: -1 is None, any other negative length or one past the record is an error
+            bad = bad || v < -1 || p > size || (uint32_t)(v < 0 ? 0 : v) > size - p;
+            uint32_t off = p;
+            p += !bad && v > 0 ? (uint32_t)v : 0u;
+            if (i == 3) {
+                klen = v;
+                o_key = off;
+            } else if (i == 4) {
+                vlen = v;
+                o_val = off;
+            } else if (!(i & 1)) {
+                kl = v;
+                ko = off;
+            } else {
+                htab[(i - 7) >> 1] = u32x4{ko, (uint32_t)kl, off, (uint32_t)v};
+            }
+        }
+    }
+    if (noted < kShapeChecks) tab[noted] = u32x4{cur_off, cur_mask, cur_pat, 0};
+    noted++;
+    // pad to an even number with a compare that always holds
+    if (noted < kShapeChecks && (noted & 1)) tab[noted] = u32x4{0, 0, 0, 0};
+    int st = kWalkDone;
+    // a varint too wide for the fast decode may be valid: the slower walk decides
+    if (wide || hc > kShapeHdrs || noted > kShapeChecks) st = kWalkGlobal;
+    // the fields must end exactly where the length said
+    else if (bad || p != size) st = kWalkExact;
+    out[0] = u32x4{(noted + 1) & ~1u, n_len, (uint32_t)length, o_od};
+    out[1] = u32x4{o_key, o_val, (uint32_t)klen, (uint32_t)vlen};
+    out[2] = u32x4{hc, (uint32_t)st, 0, 0};
+}
+
+// The record walk of one batch by the wave that streams it.  Each round pulls
+// the rows it is about to parse through the CRC into the LDS ring, finds up to 64
+// record starts by speculation (lane i assumes that the i-th next record starts
+// i * S bytes on and decodes the length varint there; lanes before the first one
+// whose size differs from S did start on a record), tests those records against
+// the shape in hand, learning the first one's shape when it does not fit, and
+// emits the records that fit.  On kWalkGlobal *k_out and *pos_out say where the
+// slower walk resumes.
+__device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c, HeaderRuns &runs,
+                                             BatchStream &stream, lds_u128 *tab, int lane,
+                                             uint32_t *k_out, uint32_t *pos_out) {
+    uint32_t count = uni(c.record_count[b]);
+    uint64_t rbase = uni(c.rec_base[b]);
+    uint64_t data_off = uni64(c.data_off[b]);
+    uint32_t data_len = uni(c.data_len[b]);
+    uint32_t bias = (uint32_t)(data_off - stream.grid);
+    RingView ring{stream.ring};
+    lds_u128 *htab = tab + kShapeChecks;
+    Shape shape;
+    shape.n_checks = 0;
+    shape.hc = 0;
+    // The stores of a round are issued in the next round, after that round's rows
+    // have been taken from the look-ahead queue and before the queue is refilled:
+    // the wait for the queued loads then never waits for stores just issued, and
+    // every load has a whole round to arrive in.  What is kept per lane is the
+    // record's start, its three free fields and its header slot; the rest follows
+    // from the shape, which changes only after the flush.
+    struct {
+        bool any, one_piece;
+        uint32_t m;
+        uint64_t r0, piece;
+        uint32_t start, attributes, slot;
+        int32_t ts, od;
+    } late;
+    late.any = false;
+    auto flush = [&]() {
+        if (!late.any) return;
+        late.any = false;
+        bool live = (uint32_t)lane < late.m;
+        if (live) {
+            RecordFields f;
+            f.length = shape.length;
+            f.attributes = late.attributes;
+            f.timestamp_delta = late.ts;
+            f.offset_delta = late.od;
+            f.key_off = late.start + shape.o_key;
+            f.key_len = shape.klen;
+            f.val_off = late.start + shape.o_val;
+            f.val_len = shape.vlen;
+            f.hdr_count = (int32_t)shape.hc;
+#ifndef X_NOREC
+            store_record(c, late.r0, (uint32_t)lane, f, late.slot);
+#endif
+        }
+#ifdef X_NOHDR
+        return;
+#endif
+        if (shape.hc == 0) return;
+        if (late.one_piece) {
+            uint32_t o = (late.slot - (uint32_t)late.piece) * 4;
+            for (uint32_t j = 0; j < shape.hc; j++, o += 4) {
+                u32x4 e = htab[j];
+                if (live) {
+                    put(c.hkey_off + late.piece, o, late.start + e.x);
+                    put(c.hkey_len + late.piece, o, (int32_t)e.y);
+                    put(c.hval_off + late.piece, o, late.start + e.z);
+                    put(c.hval_len + late.piece, o, (int32_t)e.w);
+                }
+            }
+        } else {
+            for (uint32_t j = 0; j < shape.hc; j++) {
+                u32x4 e = htab[j];
+                if (live) {
+                    c.hkey_off[late.slot + j] = late.start + e.x;
+                    c.hkey_len[late.slot + j] = (int32_t)e.y;
+                    c.hval_off[late.slot + j] = late.start + e.z;
+                    c.hval_len[late.slot + j] = (int32_t)e.w;
+                }
+            }
+        }
+    };
+    // how many of the first m lanes' records, counted from lane 0, have the shape in hand
+    auto fitting = [&](uint32_t at, uint32_t m) -> uint32_t {
+        if (shape.n_checks == 0) return 0;
+        uint32_t diff = 0;
+        // two compares at a time so that the LDS reads overlap
+        for (uint32_t s = 0; s < shape.n_checks; s += 2) {
+            u32x4 e0 = tab[s], e1 = tab[s + 1];
+            uint32_t w0 = ring.read32(at + e0.x), w1 = ring.read32(at + e1.x);
+            diff |= ((w0 ^ e0.z) & e0.y) | ((w1 ^ e1.z) & e1.y);
+        }
+        uint64_t fits = __ballot((uint32_t)lane < m && diff == 0);
+        return uni(~fits ? (uint32_t)__ffsll((long long)~fits) - 1 : 64);
+    };
+    // speculate only as far as the ring reaches
+    constexpr uint32_t kReach = kRingBytes - 2 * kRowBytes;
+    // the rows a round at byte p, of records of size sz, `left` records to go, reads
+    auto window = [&](uint32_t p, uint32_t sz, uint32_t left) -> uint32_t {
+        uint32_t n = left < (uint32_t)kWave ? left : (uint32_t)kWave;
+        if ((uint64_t)n * sz > kReach) n = kReach / sz;
+        return stream.row_after(data_off + p + (uint64_t)n * sz + 64);
+    };
+    uint32_t pos = 0, k = 0;
+    uint32_t S = count ? data_len / count : 0;
+    int st = kWalkDone;
+    // One pass of the loop is one round.  It first asks for the rows of the round
+    // after it, assuming that this round finds all the records it looks for; the
+    // rows arrive while the round is parsed from the ring and are moved into the
+    // ring at the end of the pass, as far as the round after turned out to need
+    // them.  (One exit from the loop, and no jumps out of nested blocks: the values
+    // that steer it then stay in scalar registers.)
+    while (k < count) {
+        pos = uni(pos);
+        S = uni(S);
+        k = uni(k);
+        if (S > kReach) {  // records the ring cannot hold
+            st = kWalkGlobal;
+            break;
+        }
+        stream.pull(window(pos, S, count - k));  // all there already, but for the first round and a new S
+        uint32_t lanes = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
+        if ((uint64_t)lanes * S > kReach) lanes = kReach / S;
+        uint32_t ahead_to = window(pos + lanes * S, S, count - k - lanes);
+        uint32_t n_ahead = ahead_to > stream.next_row ? ahead_to - stream.next_row : 0;
+        if (n_ahead > (uint32_t)kAhead) n_ahead = kAhead;
+        u32x4 q[kAhead];
+        stream.load(q, n_ahead);
+        flush();  // the stores of the round before, behind the loads: no wait in between
+        lds_order();
+        // ---- where the records start
+        uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
+        bool in = (uint32_t)lane < lanes && guess64 < data_len;
+        uint32_t start = in ? (uint32_t)guess64 : 0;
+        int32_t len = 0;
+        uint32_t used = 0;
+        bool ok = in && fast_varint(ring.read64(start + bias), used, len);
+        // the whole record lies inside the data (this also catches a varint cut short)
+        ok = ok && len >= 0 && (uint64_t)start + used + (uint32_t)len <= data_len;
+        uint32_t size = ok ? used + (uint32_t)len : 0;
+        uint64_t okmask = __ballot(ok);
+        uint64_t same = __ballot(ok && size == S);
+        uint32_t m = uni(~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64);
+        if (!(okmask & 1)) {
+            st = kWalkExact;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // as at the end of the pass
+            break;
+        }
+        if (m == 0) {
+            S = uni(size);  // lane 0 is a record, of another size: guess again with that
+        } else {
+            // ---- which of them have the shape in hand; learn the first one's if it has not
+            uint32_t at = start + bias;
+            uint32_t fit = fitting(at, m);
+            if (fit == 0) {
+                if (lane == 0) learn_shape(tab, ring, pos + bias, S);
+                lds_order();
+                const lds_u128 *in4 = htab + kShapeHdrs;
+                u32x4 a = in4[0], b4 = in4[1], c4 = in4[2];
+                st = (int)uni(c4.y);
+                shape.n_checks = st == kWalkDone ? uni(a.x) : 0;
+                shape.n_len = uni(a.y);
+                shape.length = (int32_t)uni(a.z);
+                shape.o_od = uni(a.w);
+                shape.o_key = uni(b4.x);
+                shape.o_val = uni(b4.y);
+                shape.klen = (int32_t)uni(b4.z);
+                shape.vlen = (int32_t)uni(b4.w);
+                shape.hc = uni(c4.x);
+                fit = fitting(at, m);
+                if (st == kWalkDone && fit == 0) st = kWalkExact;  // cannot happen: a record fits its own shape
+            }
+            if (st != kWalkDone) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // as at the end of the pass
+                break;
+            }
+            m = fit;
+            // ---- the free fields of the records that fit
+            uint32_t w_used;
+            int64_t ts;
+            uint64_t r1 = ring.read64(at + shape.n_len);  // attributes, then the timestamp delta
+            late.attributes = (uint32_t)r1 & 0xffu;
+            fast_varlong((uint32_t)(r1 >> 8), w_used, ts);
+            late.ts = (int32_t)ts;  // a shape's timestamp delta has at most four bytes
+            fast_varint(ring.read64(at + shape.o_od), w_used, late.od);
+            late.slot = 0;
+            late.one_piece = true;
+            late.piece = 0;
+            bool full = false;
+            if (shape.hc) {
+                bool live = (uint32_t)lane < m;
+                full = !runs.take(live ? shape.hc : 0u, m, count - k - m, lane, late.slot, late.piece,
+                                  late.one_piece);
+            }
+            if (full) {
+                if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+                k = count;  // ends the walk, the batch has its status
+            } else {
+                late.any = true;
+                late.m = m;
+                late.r0 = rbase + k;
+                late.start = start;
+                pos += m * S;
+                k += m;
+            }
+        }
+        lds_order();
+        // ---- the rows asked for at the top, as far as the next round reads
+        uint32_t need = k < count && S <= kReach ? window(pos, S, count - k) : stream.next_row;
+        uint32_t n_take = need > stream.next_row ? need - stream.next_row : 0;
+        stream.take_loaded(q, n_take < n_ahead ? n_take : n_ahead);
+        // Rows loaded and not taken are dropped.  Say that no load is outstanding
+        // here (s_waitcnt vmcnt(0); in the usual pass none is, the rows taken have
+        // arrived): otherwise the compiler, which cannot count across the loop
+        // edge, waits before every load of the next pass.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        lds_order();
+    }
+    // a shape that failed to be learnt has overwritten nothing the flush needs:
+    // learning follows the flush of its round
+    flush();
+    *k_out = k;
+    *pos_out = pos;
+    return st;
 }
 
 // One wave per batch: CRC-32C of the batch streamed just ahead of the record
 // walk through an LDS ring, so the batch is read from HBM once.  Batches of
 // kBigChunks chunks or more get their CRC from crc_chunks_kernel instead (one
-// wave cannot stream them fast enough) and are parsed from global memory.
+// wave cannot stream them fast enough) and their records from walk_global_kernel.
 constexpr uint32_t kBigChunks = 8;
 
-__global__ __launch_bounds__(64) void decode_fused_kernel(const uint8_t *blob,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_fused_kernel(const uint8_t *blob,
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
-                                                          uint64_t hdr_cap, const CrcTables *t, int dbg) {
+                                                          uint64_t hdr_cap, const CrcTables *t) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[kRingWords];
+    __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
     uint32_t b = blockIdx.x;
     int lane = threadIdx.x;
     if (b >= n) return;
     uint32_t chunks = uni(w.n_chunks[b]);
-    bool do_crc = chunks >= 1 && chunks < kBigChunks;
-    bool do_walk = uni(c.status[b]) == NISSHI_OK && !(uni(w.flags[b]) & kFlagExact) && !(dbg & 1);
+    if (chunks == 0 || chunks >= kBigChunks) return;
+    bool do_walk = uni(c.status[b]) == NISSHI_OK && !(uni(w.flags[b]) & kFlagExact);
     if (do_walk && (uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
         if (lane == 0) c.status[b] = NISSHI_CAPACITY;
         do_walk = false;
     }
     BatchStream stream;
-    stream.dbg = dbg;
     uint64_t lo = batch_off[b] + 21;
-    stream.init(blob, lo, do_crc ? lo + (uint64_t)uni(c.batch_length[b]) - 9 : lo, (lds_u32 *)ring, lane);
-    if (do_walk && !walk_batch(blob, b, c, w, hdr_cap, stream, do_crc, lane)) {
-        if (lane == 0) w.flags[b] |= kFlagExact;
+    stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
+    if (do_walk) {
+        HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
+        uint32_t k = 0, pos = 0;
+        int st = walk_streamed(b, c, runs, stream, (lds_u128 *)shape_tab, lane, &k, &pos);
+        if (lane == 0) {
+            c.hdr_count[b] = runs.total;
+            c.hdr_base[b] = runs.first_slot;
+            if (st == kWalkExact) w.flags[b] |= kFlagExact;
+            if (st == kWalkGlobal) {
+                w.flags[b] |= kFlagGlobal;
+                w.resume_k[b] = k;
+                w.resume_pos[b] = pos;
+            }
+        }
     }
-    if (do_crc) {
-        uint32_t v = stream.finish(t);
-        if (lane == 0) c.crc_computed[b] = v;
+    uint32_t v = stream.finish(t);
+    if (lane == 0) c.crc_computed[b] = v;
+}
+
+// One wave per batch the streamed walk left: batches of kBigChunks chunks or
+// more from their start, flagged ones from where the streamed walk stopped.
+__global__ __launch_bounds__(64) void walk_global_kernel(const uint8_t *blob, uint32_t n,
+                                                         nisshi_columns c, Work w, uint64_t rec_cap,
+                                                         uint64_t hdr_cap) {
+    uint32_t b = blockIdx.x;
+    int lane = threadIdx.x;
+    if (b >= n) return;
+    uint32_t flags = uni(w.flags[b]);
+    if (uni(c.status[b]) != NISSHI_OK || (flags & kFlagExact)) return;
+    bool big = uni(w.n_chunks[b]) >= kBigChunks;
+    if (!big && !(flags & kFlagGlobal)) return;
+    HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
+    uint32_t k = 0, pos = 0;
+    if (flags & kFlagGlobal) {
+        k = uni(w.resume_k[b]);
+        pos = uni(w.resume_pos[b]);
+        runs.total = uni(c.hdr_count[b]);
+        runs.first_slot = uni(c.hdr_base[b]);
+    } else if ((uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
+        if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+        return;
+    }
+    int st = walk_global(blob, b, c, runs, k, pos, lane);
+    if (lane == 0) {
+        c.hdr_count[b] = runs.total;
+        c.hdr_base[b] = runs.first_slot;
+        if (st != kWalkDone) w.flags[b] |= kFlagExact;
     }
 }
 
@@ -568,7 +954,7 @@ __global__ void exact_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, 
             }
         }
         if (st) break;
-        if (k < slots) store_record(c, rbase + k, f, (uint32_t)slot);
+        if (k < slots) store_record(c, (uint64_t)rbase + k, 0, f, (uint32_t)slot);
         hdr_total += (uint32_t)f.hdr_count;
     }
     c.status[b] = st;

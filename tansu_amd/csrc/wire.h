@@ -114,6 +114,20 @@ struct Reader {
         return window64(data, pos, len);
     }
 
+    // Unchecked reads of the ring: `at` = position + ring_bias, all bytes staged.
+    __device__ __forceinline__ uint32_t ring32(uint32_t at) const {
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+        typedef __attribute__((address_space(3))) const u32_unaligned lds_u32u;
+        typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+        return *(lds_u32u *)((lds_u8 *)ring + (at & ring_mask));
+    }
+    __device__ __forceinline__ uint64_t ring64(uint32_t at) const {
+        typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+        typedef __attribute__((address_space(3))) const u64_unaligned lds_u64;
+        typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+        return *(lds_u64 *)((lds_u8 *)ring + (at & ring_mask));
+    }
+
     __device__ __forceinline__ int varint(uint32_t &pos, int32_t &out) {
         if (pos >= len) return NISSHI_TRY_GET;
         uint32_t used = 0;
