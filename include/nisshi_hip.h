@@ -16,7 +16,7 @@
  *   From<deflated::Batch> for Bytes                 src/record/deflated.rs:84-106
  *   records-blob framing                            src/de.rs:701-720, 1056-1093; src/ser.rs:484-489, 521-574
  *
- * Decoded batches are columns (one array per field), not Vec<Record>.  Span
+ * Decoded batches are columns, not Vec<Record>.  Span
  * offsets are relative to the batch's record_data, mirroring the zero-copy
  * Bytes::split_to slices of the reference (src/record/codec.rs:65-76): a null
  * Option<Bytes> has length -1 and the offset where its bytes would start.
@@ -49,6 +49,31 @@ enum {
     NISSHI_INVALID_ARGUMENT = 9
 };
 
+/* Decoded records are columns, grouped so that the fields the decoder produces
+ * together are stored together: per record a 16-byte key group, a 16-byte value
+ * group, the timestamp delta and the attributes (41 bytes, record.rs:172-198),
+ * per header one 16-byte group (header.rs:21-29). */
+typedef struct nisshi_record_key {
+    int32_t length; /* as on the wire; never used to delimit the record */
+    int32_t offset_delta;
+    uint32_t key_off;
+    int32_t key_len; /* -1: None */
+} nisshi_record_key;
+
+typedef struct nisshi_record_value {
+    uint32_t val_off;
+    int32_t val_len;   /* -1: None */
+    uint32_t hdr_base; /* slot of the record's first header; a record's headers are contiguous */
+    int32_t hdr_count;
+} nisshi_record_value;
+
+typedef struct nisshi_header_span {
+    uint32_t key_off;
+    int32_t key_len; /* -1: None */
+    uint32_t val_off;
+    int32_t val_len; /* -1: None */
+} nisshi_header_span;
+
 /* One pointer per column.  For the *_dev entry points these are device
  * pointers; for the host entry points host pointers.  Field order is ABI. */
 typedef struct nisshi_columns {
@@ -74,22 +99,13 @@ typedef struct nisshi_columns {
     uint32_t *hdr_base;  /* slot of the batch's first header (its headers need not be one run) */
     uint32_t *hdr_count; /* headers in the batch */
     int32_t *status;
-    /* per record (record.rs:172-198) */
-    int32_t *length;
-    uint8_t *rattributes;
+    /* per record */
+    nisshi_record_key *rkey;
+    nisshi_record_value *rval;
     int64_t *timestamp_delta;
-    int32_t *offset_delta;
-    uint32_t *key_off;
-    int32_t *key_len;
-    uint32_t *val_off;
-    int32_t *val_len;
-    uint32_t *rhdr_base; /* slot of the record's first header; a record's headers are contiguous */
-    int32_t *rhdr_count;
-    /* per header (header.rs:21-29) */
-    uint32_t *hkey_off;
-    int32_t *hkey_len;
-    uint32_t *hval_off;
-    int32_t *hval_len;
+    uint8_t *rattributes;
+    /* per header */
+    nisshi_header_span *hdr;
 } nisshi_columns;
 
 typedef struct nisshi_totals {
@@ -135,7 +151,7 @@ int nisshi_hip_count_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t bl
  * status and no valid records; the call still returns NISSHI_OK.
  *
  * Header slots are handed out in runs from one cursor while batches decode in
- * parallel: a record's headers are contiguous from rhdr_base, but the order of
+ * parallel: a record's headers are contiguous from hdr_base, but the order of
  * runs between batches is not defined and a batch may leave up to 4096 slots of
  * its last run unused, so size hdr_cap with that slack (a batch whose headers
  * do not fit gets NISSHI_CAPACITY).  Batches whose records all carry the same

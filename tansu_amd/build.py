@@ -33,6 +33,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    # extra compiler flags for diagnostic builds, e.g. NISSHI_CXXFLAGS=-DNISSHI_PHASES
+    cmd[1:1] = os.environ.get("NISSHI_CXXFLAGS", "").split()
     subprocess.check_call(cmd)
     return LIB
 

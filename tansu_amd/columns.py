@@ -1,11 +1,14 @@
-"""Column (SoA) layout of decoded record batches, and conversions to and from the
-record shape the reference uses.
+"""Columns of decoded record batches, and conversions to and from the record
+shape the reference uses.
 
-The layout is the one `include/nisshi_hip.h` declares as `nisshi_columns`: one
-array per field, per batch, per record and per header.  Span offsets are
-relative to the start of the batch's `record_data`, as `Bytes::split_to` spans
-are in the reference (nisshi-sans-io/src/record/codec.rs:65-76); a null span
-has length -1 and keeps the offset where its bytes would have started.
+Host code here works on one numpy array per field ("fields": BATCH_COLUMNS,
+RECORD_COLUMNS, HEADER_COLUMNS).  The device library stores the per-record and
+per-header fields in groups of 16 bytes, as `include/nisshi_hip.h` declares in
+`nisshi_columns` (GROUPS below); `pack` and `unpack` convert between the two.
+Span offsets are relative to the start of the batch's `record_data`, as
+`Bytes::split_to` spans are in the reference
+(nisshi-sans-io/src/record/codec.rs:65-76); a null span has length -1 and keeps
+the offset where its bytes would have started.
 
 Everything here is host-side bookkeeping on numpy arrays: no decoding or
 encoding of wire bytes happens in this module.
@@ -75,9 +78,71 @@ RECORD_BYTES = 41
 HEADER_BYTES = 16
 
 
+# The groups of `nisshi_columns`: (array name, fields stored together as four
+# 32-bit words).  timestamp_delta and rattributes are arrays of their own.
+RECORD_GROUPS = [
+    ("rkey", ["length", "offset_delta", "key_off", "key_len"]),
+    ("rval", ["val_off", "val_len", "rhdr_base", "rhdr_count"]),
+]
+HEADER_GROUPS = [
+    ("hdr", ["hkey_off", "hkey_len", "hval_off", "hval_len"]),
+]
+# arrays of the device layout, in the order of the C struct: (name, dtype, words per row, level)
+DEVICE_ARRAYS = ([(n, dt, 1, 0) for n, dt in BATCH_COLUMNS] +
+                 [("rkey", np.int32, 4, 1), ("rval", np.int32, 4, 1),
+                  ("timestamp_delta", np.int64, 1, 1), ("rattributes", np.uint8, 1, 1),
+                  ("hdr", np.int32, 4, 2)])
+_FIELD_DTYPE = dict(ALL_COLUMNS)
+
+
 class CColumns(ctypes.Structure):
-    """ctypes view of `nisshi_columns`: one pointer per column."""
-    _fields_ = [(name, ctypes.c_void_p) for name, _ in ALL_COLUMNS]
+    """ctypes view of `nisshi_columns`: one pointer per array of the device layout."""
+    _fields_ = [(name, ctypes.c_void_p) for name, _, _, _ in DEVICE_ARRAYS]
+
+
+def alloc_device_layout(n_batches: int, n_records: int, n_headers: int) -> dict:
+    """Host arrays in the device layout (for the host-buffer entry points)."""
+    counts = (n_batches, n_records, n_headers)
+    out = {}
+    for name, dt, words, level in DEVICE_ARRAYS:
+        n = max(counts[level], 1)
+        out[name] = np.zeros((n, words) if words > 1 else n, dtype=dt)
+    return out
+
+
+def as_c(arrays: dict) -> CColumns:
+    """Pointers to host arrays in the device layout (keep `arrays` alive while in use)."""
+    c = CColumns()
+    for name, _, _, _ in DEVICE_ARRAYS:
+        setattr(c, name, arrays[name].ctypes.data)
+    return c
+
+
+def pack(cols: dict) -> dict:
+    """Fields -> device layout."""
+    out = {n: np.ascontiguousarray(cols[n]) for n, _ in BATCH_COLUMNS}
+    for name, fields in RECORD_GROUPS + HEADER_GROUPS:
+        n = len(cols[fields[0]])
+        g = np.zeros((max(n, 1), 4), dtype=np.int32)
+        for i, f in enumerate(fields):
+            g[:n, i] = np.asarray(cols[f]).view(np.int32) if np.asarray(cols[f]).dtype.itemsize == 4 \
+                else np.asarray(cols[f]).astype(np.int32)
+        out[name] = g
+    out["timestamp_delta"] = np.ascontiguousarray(cols["timestamp_delta"])
+    out["rattributes"] = np.ascontiguousarray(cols["rattributes"])
+    return out
+
+
+def unpack(arrays: dict) -> dict:
+    """Device layout -> fields."""
+    out = {n: arrays[n] for n, _ in BATCH_COLUMNS}
+    for name, fields in RECORD_GROUPS + HEADER_GROUPS:
+        g = np.asarray(arrays[name]).reshape(-1, 4)
+        for i, f in enumerate(fields):
+            out[f] = np.ascontiguousarray(g[:, i]).view(_FIELD_DTYPE[f])
+    out["timestamp_delta"] = arrays["timestamp_delta"]
+    out["rattributes"] = arrays["rattributes"]
+    return out
 
 
 def alloc_host(n_batches: int, n_records: int, n_headers: int) -> dict:
@@ -89,14 +154,6 @@ def alloc_host(n_batches: int, n_records: int, n_headers: int) -> dict:
     for name, dt in HEADER_COLUMNS:
         cols[name] = np.zeros(max(n_headers, 1), dtype=dt)
     return cols
-
-
-def as_c(cols: dict) -> CColumns:
-    """Pointers to host numpy arrays (keep `cols` alive while the struct is in use)."""
-    c = CColumns()
-    for name, _ in ALL_COLUMNS:
-        setattr(c, name, cols[name].ctypes.data)
-    return c
 
 
 def trim(cols: dict, n_batches: int, n_records: int, n_headers: int) -> dict:

@@ -236,21 +236,21 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u128;
 
 struct BatchStream {
-    const uint8_t *base;
-    uint64_t grid, lo, hi;
+    // Offsets are relative to `grid`, the 16-byte boundary at or below the first
+    // byte: the stream handles at most 4 GiB.
+    uint32_t lo, hi;          // the bytes [lo, hi) are the data; lo < 16
     uint32_t rows, next_row;
     uint32_t acc[4];
     lds_u32 *ring;
     int lane;
     const uint8_t *lane_ptr;  // this lane's 16 bytes of row 0
 
-    __device__ __forceinline__ void init(const uint8_t *base_, uint64_t lo_, uint64_t hi_,
+    __device__ __forceinline__ void init(const uint8_t *base, uint64_t lo_, uint64_t hi_,
                                          lds_u32 *ring_, int lane_) {
-        base = base_;
-        lo = uni64(lo_);
-        hi = uni64(hi_);
-        grid = lo & ~uint64_t(15);
-        rows = (uint32_t)((hi - grid + kRowBytes - 1) / kRowBytes);
+        uint64_t grid = uni64(lo_) & ~uint64_t(15);
+        lo = (uint32_t)(uni64(lo_) - grid);
+        hi = (uint32_t)(uni64(hi_) - grid);
+        rows = (hi + kRowBytes - 1) / kRowBytes;
         next_row = 0;
         ring = ring_;
         lane = lane_;
@@ -258,11 +258,10 @@ struct BatchStream {
         acc[0] = acc[1] = acc[2] = acc[3] = 0;
     }
 
-    // first row index that does not touch absolute offset < `addr`
-    __device__ __forceinline__ uint32_t row_after(uint64_t addr) const {
-        if (addr <= grid) return 0;
-        uint64_t r = (addr - grid + kRowBytes - 1) / kRowBytes;
-        return r < rows ? (uint32_t)r : rows;
+    // first row that does not touch a byte below offset `x`
+    __device__ __forceinline__ uint32_t row_after(uint32_t x) const {
+        uint32_t r = (x + kRowBytes - 1) / kRowBytes;
+        return r < rows ? r : rows;
     }
 
     __device__ __forceinline__ bool edge(uint32_t r) const { return r == 0 || r + 1 >= rows; }
@@ -272,12 +271,10 @@ struct BatchStream {
     // last) re-read the last 16 data bytes instead, and fix_edge() discards what
     // they got.
     __device__ __forceinline__ const uint8_t *row_ptr(uint32_t r) const {
-        const uint8_t *p = lane_ptr + (uint64_t)r * kRowBytes;
-        if (r + 1 >= rows) {
-            const uint8_t *last = base + ((hi - 1) & ~uint64_t(15));
-            p = p < last ? p : last;
-        }
-        return p;
+        uint32_t off = r * kRowBytes + (uint32_t)lane * 16;
+        uint32_t last = (hi - 1) & ~15u;
+        off = off < last ? off : last;
+        return lane_ptr + (int64_t)((int32_t)off - lane * 16);
     }
 
     __device__ __forceinline__ u32x4 fetch(uint32_t r) const {
@@ -301,7 +298,7 @@ struct BatchStream {
     __device__ __forceinline__ void fix_edge(uint32_t r) {
         uint32_t slot = r & (kRingRows - 1);
         u32x4 raw = *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4);
-        uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
+        uint64_t addr = (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             uint32_t fix = raw[i] & ~byte_mask(addr + 4 * i, lo, hi);
@@ -317,8 +314,14 @@ struct BatchStream {
     __device__ __forceinline__ void load(u32x4 (&q)[kAhead], uint32_t n) const {
         typedef __attribute__((address_space(1))) const u32x4 gbl_u128;  // global, not flat
         gbl_u128 *p[kAhead];
+        if (next_row + kAhead < rows) {  // none of them is the last row: no clamp
 #pragma unroll
-        for (int j = 0; j < kAhead; j++) p[j] = (gbl_u128 *)(uintptr_t)row_ptr(next_row + j);
+            for (int j = 0; j < kAhead; j++)
+                p[j] = (gbl_u128 *)(uintptr_t)(lane_ptr + (uint64_t)(next_row + j) * kRowBytes);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kAhead; j++) p[j] = (gbl_u128 *)(uintptr_t)row_ptr(next_row + j);
+        }
 #pragma unroll
         for (int j = 0; j < kAhead; j++) asm volatile("" : "+v"(p[j]));
 #pragma unroll
@@ -352,21 +355,12 @@ struct BatchStream {
         }
     }
 
-    // bytes currently in the ring, as absolute offsets [from, to)
-    __device__ __forceinline__ uint64_t staged_from() const {
-        uint32_t first = next_row > (uint32_t)kRingRows ? next_row - kRingRows : 0;
-        return grid + (uint64_t)first * kRowBytes;
-    }
-    __device__ __forceinline__ uint64_t staged_to() const {
-        return grid + (uint64_t)next_row * kRowBytes;
-    }
-
     // the CRC-32C of [lo, hi)
     __device__ __forceinline__ uint32_t finish(const CrcTables *t) {
         pull(rows);
         if (hi == lo) return 0;
         uint32_t r = crc_row_residue(acc, lane, t);
-        uint64_t pad = grid + (uint64_t)rows * kRowBytes - hi;
+        uint32_t pad = rows * kRowBytes - hi;
         return ~gf_mulmod(r, t->inv8[pad]);
     }
 };

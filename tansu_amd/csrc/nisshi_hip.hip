@@ -251,22 +251,25 @@ __device__ __forceinline__ void put(T *base, uint32_t byte_off, T v) {
     *reinterpret_cast<T *>(reinterpret_cast<uint8_t *>(base) + byte_off) = v;
 }
 
-// The record at index r0 + lane; r0 is uniform.
+// The record at index r0 + lane; r0 is uniform.  Each group of fields is one
+// store of 16 bytes a lane.
 __device__ __forceinline__ void store_record(const nisshi_columns &c, uint64_t r0, uint32_t lane,
                                              const RecordFields &f, uint32_t hdr_slot) {
     // the lane's share of the addresses is cheap to form here; left visible, the
     // compiler keeps one 64-bit pointer per column and lane alive across the walk
     asm volatile("" : "+v"(lane));
-    put(c.length + r0, lane * 4, f.length);
-    put(c.rattributes + r0, lane, (uint8_t)f.attributes);
+    put(reinterpret_cast<u32x4 *>(c.rkey + r0), lane * 16,
+        u32x4{(uint32_t)f.length, (uint32_t)f.offset_delta, f.key_off, (uint32_t)f.key_len});
+    put(reinterpret_cast<u32x4 *>(c.rval + r0), lane * 16,
+        u32x4{f.val_off, (uint32_t)f.val_len, hdr_slot, (uint32_t)f.hdr_count});
     put(c.timestamp_delta + r0, lane * 8, f.timestamp_delta);
-    put(c.offset_delta + r0, lane * 4, f.offset_delta);
-    put(c.key_off + r0, lane * 4, f.key_off);
-    put(c.key_len + r0, lane * 4, f.key_len);
-    put(c.val_off + r0, lane * 4, f.val_off);
-    put(c.val_len + r0, lane * 4, f.val_len);
-    put(c.rhdr_base + r0, lane * 4, hdr_slot);
-    put(c.rhdr_count + r0, lane * 4, f.hdr_count);
+    put(c.rattributes + r0, lane, (uint8_t)f.attributes);
+}
+
+// One header's spans at `slot`.
+__device__ __forceinline__ void store_header(const nisshi_columns &c, uint64_t slot, uint32_t ko,
+                                             int32_t kl, uint32_t vo, int32_t vl) {
+    *reinterpret_cast<u32x4 *>(c.hdr + slot) = u32x4{ko, (uint32_t)kl, vo, (uint32_t)vl};
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
@@ -461,10 +464,7 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
                 ok = ok && vl >= -1 && p <= end && (uint32_t)(vl < 0 ? 0 : vl) <= end - p;
                 p += ok && vl > 0 ? (uint32_t)vl : 0u;
                 if (ok) {
-                    c.hkey_off[slot + j] = ko;
-                    c.hkey_len[slot + j] = kl;
-                    c.hval_off[slot + j] = vo;
-                    c.hval_len[slot + j] = vl;
+                    store_header(c, slot + j, ko, kl, vo, vl);
                 }
             }
         }
@@ -614,9 +614,9 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                                              uint32_t *k_out, uint32_t *pos_out) {
     uint32_t count = uni(c.record_count[b]);
     uint64_t rbase = uni(c.rec_base[b]);
-    uint64_t data_off = uni64(c.data_off[b]);
     uint32_t data_len = uni(c.data_len[b]);
-    uint32_t bias = (uint32_t)(data_off - stream.grid);
+    // the record data's offset in the stream: data_off - (batch start + 21) + stream.lo
+    uint32_t bias = 40 + stream.lo;
     RingView ring{stream.ring};
     lds_u128 *htab = tab + kShapeChecks;
     Shape shape;
@@ -651,34 +651,21 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             f.val_off = late.start + shape.o_val;
             f.val_len = shape.vlen;
             f.hdr_count = (int32_t)shape.hc;
-#ifndef X_NOREC
             store_record(c, late.r0, (uint32_t)lane, f, late.slot);
-#endif
         }
-#ifdef X_NOHDR
-        return;
-#endif
         if (shape.hc == 0) return;
         if (late.one_piece) {
-            uint32_t o = (late.slot - (uint32_t)late.piece) * 4;
-            for (uint32_t j = 0; j < shape.hc; j++, o += 4) {
+            uint32_t o = (late.slot - (uint32_t)late.piece) * 16;
+            for (uint32_t j = 0; j < shape.hc; j++, o += 16) {
                 u32x4 e = htab[j];
-                if (live) {
-                    put(c.hkey_off + late.piece, o, late.start + e.x);
-                    put(c.hkey_len + late.piece, o, (int32_t)e.y);
-                    put(c.hval_off + late.piece, o, late.start + e.z);
-                    put(c.hval_len + late.piece, o, (int32_t)e.w);
-                }
+                if (live)
+                    put(reinterpret_cast<u32x4 *>(c.hdr + late.piece), o,
+                        u32x4{late.start + e.x, e.y, late.start + e.z, e.w});
             }
         } else {
             for (uint32_t j = 0; j < shape.hc; j++) {
                 u32x4 e = htab[j];
-                if (live) {
-                    c.hkey_off[late.slot + j] = late.start + e.x;
-                    c.hkey_len[late.slot + j] = (int32_t)e.y;
-                    c.hval_off[late.slot + j] = late.start + e.z;
-                    c.hval_len[late.slot + j] = (int32_t)e.w;
-                }
+                if (live) store_header(c, late.slot + j, late.start + e.x, (int32_t)e.y, late.start + e.z, (int32_t)e.w);
             }
         }
     };
@@ -697,15 +684,27 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     };
     // speculate only as far as the ring reaches
     constexpr uint32_t kReach = kRingBytes - 2 * kRowBytes;
-    // the rows a round at byte p, of records of size sz, `left` records to go, reads
-    auto window = [&](uint32_t p, uint32_t sz, uint32_t left) -> uint32_t {
-        uint32_t n = left < (uint32_t)kWave ? left : (uint32_t)kWave;
-        if ((uint64_t)n * sz > kReach) n = kReach / sz;
-        return stream.row_after(data_off + p + (uint64_t)n * sz + 64);
+    // the rows a round at byte p reads: `left` records to go, of size sz, at most
+    // `cap` of them within the ring's reach
+    auto window = [&](uint32_t p, uint32_t sz, uint32_t cap, uint32_t left) -> uint32_t {
+        uint32_t n = left < cap ? left : cap;
+        return stream.row_after(bias + p + n * sz + 64);
+    };
+    auto reach = [&](uint32_t sz) -> uint32_t {  // records of size sz a round can hold
+        uint32_t n = sz ? kReach / sz : (uint32_t)kWave;
+        return n < (uint32_t)kWave ? n : (uint32_t)kWave;
     };
     uint32_t pos = 0, k = 0;
     uint32_t S = count ? data_len / count : 0;
+    uint32_t cap = reach(S);
     int st = kWalkDone;
+#ifdef NISSHI_PHASES
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tmark = __builtin_readcyclecounter();
+#define PHASE(i) { uint64_t now_ = __builtin_readcyclecounter(); ph[i] += now_ - tmark; tmark = now_; }
+#else
+#define PHASE(i)
+#endif
     // One pass of the loop is one round.  It first asks for the rows of the round
     // after it, assuming that this round finds all the records it looks for; the
     // rows arrive while the round is parsed from the ring and are moved into the
@@ -716,20 +715,24 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         pos = uni(pos);
         S = uni(S);
         k = uni(k);
+        cap = uni(cap);
         if (S > kReach) {  // records the ring cannot hold
             st = kWalkGlobal;
             break;
         }
-        stream.pull(window(pos, S, count - k));  // all there already, but for the first round and a new S
-        uint32_t lanes = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
-        if ((uint64_t)lanes * S > kReach) lanes = kReach / S;
-        uint32_t ahead_to = window(pos + lanes * S, S, count - k - lanes);
+        PHASE(0)
+        stream.pull(window(pos, S, cap, count - k));  // all there already, but for the first round and a new S
+        PHASE(1)
+        uint32_t lanes = count - k < cap ? count - k : cap;
+        uint32_t ahead_to = window(pos + lanes * S, S, cap, count - k - lanes);
         uint32_t n_ahead = ahead_to > stream.next_row ? ahead_to - stream.next_row : 0;
         if (n_ahead > (uint32_t)kAhead) n_ahead = kAhead;
         u32x4 q[kAhead];
         stream.load(q, n_ahead);
+        PHASE(2)
         flush();  // the stores of the round before, behind the loads: no wait in between
         lds_order();
+        PHASE(3)
         // ---- where the records start
         uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
         bool in = (uint32_t)lane < lanes && guess64 < data_len;
@@ -748,8 +751,10 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             __builtin_amdgcn_s_waitcnt(0x0F70);  // as at the end of the pass
             break;
         }
+        PHASE(4)
         if (m == 0) {
             S = uni(size);  // lane 0 is a record, of another size: guess again with that
+            cap = reach(S);
         } else {
             // ---- which of them have the shape in hand; learn the first one's if it has not
             uint32_t at = start + bias;
@@ -777,6 +782,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                 break;
             }
             m = fit;
+            PHASE(5)
             // ---- the free fields of the records that fit
             uint32_t w_used;
             int64_t ts;
@@ -807,8 +813,9 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             }
         }
         lds_order();
+        PHASE(6)
         // ---- the rows asked for at the top, as far as the next round reads
-        uint32_t need = k < count && S <= kReach ? window(pos, S, count - k) : stream.next_row;
+        uint32_t need = k < count && S <= kReach ? window(pos, S, cap, count - k) : stream.next_row;
         uint32_t n_take = need > stream.next_row ? need - stream.next_row : 0;
         stream.take_loaded(q, n_take < n_ahead ? n_take : n_ahead);
         // Rows loaded and not taken are dropped.  Say that no load is outstanding
@@ -817,7 +824,12 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         // edge, waits before every load of the next pass.
         __builtin_amdgcn_s_waitcnt(0x0F70);
         lds_order();
+        PHASE(7)
     }
+#ifdef NISSHI_PHASES
+    if (lane == 0 && (b % 1024) == 7)
+        printf("b=%u other=%lu pull=%lu load=%lu flush=%lu spec=%lu fit=%lu emit=%lu take=%lu\n", b, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+#endif
     // a shape that failed to be learnt has overwritten nothing the flush needs:
     // learning follows the flush of its round
     flush();
@@ -947,10 +959,7 @@ __global__ void exact_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, 
             if ((st = rd.octets(pos, ko, kl))) break;
             if ((st = rd.octets(pos, vo, vl))) break;
             if (keep) {
-                c.hkey_off[slot + j] = ko;
-                c.hkey_len[slot + j] = kl;
-                c.hval_off[slot + j] = vo;
-                c.hval_len[slot + j] = vl;
+                store_header(c, slot + j, ko, kl, vo, vl);
             }
         }
         if (st) break;

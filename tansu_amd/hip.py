@@ -107,43 +107,49 @@ def _torch_dtype(np_dtype):
 
 
 class DeviceColumns:
-    """Columns resident in device memory (torch tensors, one per column)."""
+    """Columns resident in device memory: one torch tensor per array of the device
+    layout (`t`), batch columns by field name, records and headers in their groups."""
 
     def __init__(self, n_batches: int, rec_cap: int, hdr_cap: int, device):
         import torch
         self.n_batches, self.rec_cap, self.hdr_cap = n_batches, rec_cap, hdr_cap
+        counts = (n_batches, rec_cap, hdr_cap)
         self.t = {}
-        for group, n in ((C.BATCH_COLUMNS, n_batches), (C.RECORD_COLUMNS, rec_cap),
-                         (C.HEADER_COLUMNS, hdr_cap)):
-            for name, dt in group:
-                self.t[name] = torch.empty(max(n, 1), dtype=_torch_dtype(dt), device=device)
         self.c = C.CColumns()
-        for name, _ in C.ALL_COLUMNS:
+        for name, dt, words, level in C.DEVICE_ARRAYS:
+            n = max(counts[level], 1)
+            self.t[name] = torch.empty((n, words) if words > 1 else n, dtype=_torch_dtype(dt),
+                                       device=device)
             setattr(self.c, name, self.t[name].data_ptr())
+
+    def field(self, name: str):
+        """The device tensor (a strided view, for grouped fields) of one field."""
+        for gname, fields in C.RECORD_GROUPS + C.HEADER_GROUPS:
+            if name in fields:
+                return self.t[gname][:, fields.index(name)]
+        return self.t[name]
 
     @classmethod
     def from_host(cls, cols: dict, device):
+        """From one numpy array per field."""
         import torch
-        n_b = len(cols["status"])
-        n_r = len(cols["length"])
-        n_h = len(cols["hkey_off"])
-        self = cls(n_b, n_r, n_h, device)
-        for name, dt in C.ALL_COLUMNS:
-            src = np.ascontiguousarray(cols[name])
-            if len(src):
-                signed = src.view(np.dtype(f"i{src.dtype.itemsize}"))
-                self.t[name][:len(src)].copy_(torch.from_numpy(signed.copy()))
+        self = cls(len(cols["status"]), len(cols["length"]), len(cols["hkey_off"]), device)
+        for name, arr in C.pack(cols).items():
+            n = len(cols[{"rkey": "length", "rval": "length", "hdr": "hkey_off"}.get(name, name)])
+            if n:
+                signed = np.ascontiguousarray(arr[:n]).view(np.dtype(f"i{arr.dtype.itemsize}"))
+                self.t[name][:n].copy_(torch.from_numpy(signed.copy()))
         return self
 
     def to_host(self, n_records: Optional[int] = None, n_headers: Optional[int] = None) -> dict:
+        """One numpy array per field."""
         n_records = self.rec_cap if n_records is None else n_records
         n_headers = self.hdr_cap if n_headers is None else n_headers
-        out = {}
-        for group, n in ((C.BATCH_COLUMNS, self.n_batches), (C.RECORD_COLUMNS, n_records),
-                         (C.HEADER_COLUMNS, n_headers)):
-            for name, dt in group:
-                out[name] = self.t[name][:n].cpu().numpy().view(dt).copy()
-        return out
+        counts = (self.n_batches, n_records, n_headers)
+        arrays = {}
+        for name, dt, words, level in C.DEVICE_ARRAYS:
+            arrays[name] = self.t[name][:counts[level]].cpu().numpy().view(dt).copy()
+        return C.unpack(arrays)
 
 
 class Codec:
@@ -251,12 +257,13 @@ class Codec:
         n_b = len(off) - 1
         rec_cap = len(arr) // 7 + 1 if rec_cap is None else rec_cap
         hdr_cap = len(arr) // 2 + 1 if hdr_cap is None else hdr_cap
-        cols = C.alloc_host(n_b, rec_cap, hdr_cap)
-        cc = C.as_c(cols)
+        arrays = C.alloc_device_layout(n_b, rec_cap, hdr_cap)
+        cc = C.as_c(arrays)
         totals = Totals()
         self._check(self.lib.nisshi_hip_decode(
             self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data, n_b,
             int(by_value), ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(totals)))
+        cols = C.unpack(arrays)
         return C.trim(cols, n_b, min(totals.n_records, rec_cap), min(totals.n_headers, hdr_cap)), totals
 
     def encode(self, cols: dict, src: bytes, src_data_off, out_cap: Optional[int] = None):
@@ -268,8 +275,8 @@ class Codec:
             out_cap = 2 * len(sarr) + 128 * n_b + 64 * len(cols["length"]) + 1024
         out = np.zeros(out_cap, dtype=np.uint8)
         out_off = np.zeros(n_b + 1, dtype=np.uint64)
-        full = {k: np.ascontiguousarray(v) for k, v in cols.items()}
-        full = {k: (v if len(v) else np.zeros(1, dtype=v.dtype)) for k, v in full.items()}
+        full = C.pack(cols)
+        full = {k: (v if len(v) else np.zeros((1,) + v.shape[1:], dtype=v.dtype)) for k, v in full.items()}
         cc = C.as_c(full)
         totals = Totals()
         self._check(self.lib.nisshi_hip_encode(

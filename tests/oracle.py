@@ -18,6 +18,19 @@ def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libnisshi_oracle.so"])
 
 
+class FieldColumns(ctypes.Structure):
+    """ctypes view of the oracle's `no_columns`: one pointer per field."""
+    _fields_ = [(name, ctypes.c_void_p) for name, _ in C.ALL_COLUMNS]
+
+
+def as_c(cols: dict) -> FieldColumns:
+    """Pointers to one numpy array per field (keep `cols` alive while in use)."""
+    c = FieldColumns()
+    for name, _ in C.ALL_COLUMNS:
+        setattr(c, name, cols[name].ctypes.data)
+    return c
+
+
 def _load():
     src = os.path.join(ORACLE_DIR, "nisshi_oracle.c")
     if not os.path.exists(LIB_PATH) or (
@@ -55,11 +68,11 @@ def _load():
     lib.no_records_prefix_encode.restype = sz
     lib.no_records_prefix_encode.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
     lib.no_decode_columns.argtypes = [ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_int,
-                                      ctypes.POINTER(C.CColumns), sz, sz,
+                                      ctypes.POINTER(FieldColumns), sz, sz,
                                       ctypes.POINTER(sz), ctypes.POINTER(sz)]
-    lib.no_encode_columns.argtypes = [ctypes.POINTER(C.CColumns), sz, ctypes.c_void_p,
+    lib.no_encode_columns.argtypes = [ctypes.POINTER(FieldColumns), sz, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_void_p]
-    lib.no_builder_columns.argtypes = [ctypes.POINTER(C.CColumns), sz, ctypes.c_void_p,
+    lib.no_builder_columns.argtypes = [ctypes.POINTER(FieldColumns), sz, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
@@ -118,7 +131,7 @@ def decode_columns(blob, batch_off, by_value=True, rec_cap=None, hdr_cap=None):
     if hdr_cap is None:
         hdr_cap = len(blob) // 2 + 1
     cols = C.alloc_host(n_b, rec_cap, hdr_cap)
-    cc = C.as_c(cols)
+    cc = as_c(cols)
     nr, nh = ctypes.c_size_t(0), ctypes.c_size_t(0)
     st = LIB.no_decode_columns(blob.ctypes.data, batch_off.ctypes.data, n_b, int(by_value),
                                ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(nr),
@@ -134,7 +147,7 @@ def encode_columns(cols, n_batches, src, src_data_off, out_cap=None):
         out_cap = len(src) * 2 + 128 * n_batches + 1024
     out = np.zeros(out_cap, dtype=np.uint8)
     out_off = np.zeros(n_batches + 1, dtype=np.uint64)
-    cc = C.as_c(cols)
+    cc = as_c(cols)
     st = LIB.no_encode_columns(ctypes.byref(cc), n_batches, src.ctypes.data,
                                src_data_off.ctypes.data, out.ctypes.data, out_cap,
                                out_off.ctypes.data)
@@ -148,7 +161,7 @@ def builder_columns(cols, n_batches, src, src_data_off):
     src_data_off = np.ascontiguousarray(src_data_off, dtype=np.uint64)
     bl = np.zeros(max(n_batches, 1), dtype=np.int32)
     crc = np.zeros(max(n_batches, 1), dtype=np.uint32)
-    cc = C.as_c(cols)
+    cc = as_c(cols)
     st = LIB.no_builder_columns(ctypes.byref(cc), n_batches, src.ctypes.data,
                                 src_data_off.ctypes.data, bl.ctypes.data, crc.ctypes.data)
     return st, bl[:n_batches], crc[:n_batches]

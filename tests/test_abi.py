@@ -37,11 +37,27 @@ def test_columns_struct_matches_header():
     body = text[text.index("typedef struct nisshi_columns {"):text.index("} nisshi_columns;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"\*(\w+);", body)
-    assert fields == [n for n, _ in C.ALL_COLUMNS]
+    assert fields == [n for n, _, _, _ in C.DEVICE_ARRAYS]
     ctypes_by_np = {np.int64: "int64_t", np.int32: "int32_t", np.int16: "int16_t", np.int8: "int8_t",
                     np.uint64: "uint64_t", np.uint32: "uint32_t", np.uint8: "uint8_t"}
-    for name, dt in C.ALL_COLUMNS:
-        assert re.search(rf"{ctypes_by_np[dt]} \*{name};", body), name
+    groups = dict(C.RECORD_GROUPS + C.HEADER_GROUPS)
+    struct_of = {"rkey": "nisshi_record_key", "rval": "nisshi_record_value", "hdr": "nisshi_header_span"}
+    field_dt = dict(C.ALL_COLUMNS)
+    for name, dt, words, _ in C.DEVICE_ARRAYS:
+        if words == 1:
+            assert re.search(rf"{ctypes_by_np[dt]} \*{name};", body), name
+            continue
+        # a group: four 32-bit fields, in the order the Python side packs them
+        assert re.search(rf"{struct_of[name]} \*{name};", body), name
+        sbody = text[text.index(f"typedef struct {struct_of[name]} {{"):text.index(f"}} {struct_of[name]};")]
+        sbody = re.sub(r"/\*.*?\*/", "", sbody, flags=re.S)
+        got = re.findall(r"(u?int32_t) (\w+);", sbody)
+        want = groups[name]
+        assert len(got) == 4
+        for (ctype, cname), fname in zip(got, want):
+            assert ctype == ctypes_by_np[field_dt[fname]], (name, fname)
+            # C names drop the prefix that tells records' and headers' fields apart
+            assert fname.endswith(cname.replace("hdr_", "rhdr_")) or fname == cname or fname.endswith(cname), (cname, fname)
 
 
 def test_status_strings(lib):

@@ -330,14 +330,15 @@ def test_full_size_properties(codec, name):
     t = cols.t
     assert bool((t["status"] == 0).all()) and bool((t["crc"] == t["crc_computed"]).all())
     r = int(counts[0])
-    od = t["offset_delta"][:nr].view(n_b, r)
+    f = cols.field
+    od = f("offset_delta")[:nr].reshape(n_b, r)
     assert bool((od == torch.arange(r, device=od.device, dtype=od.dtype)).all())
-    assert bool((t["timestamp_delta"][:nr].view(n_b, r) == torch.arange(r, device=od.device)).all())
-    assert bool((t["val_len"][:nr] == shape.val_len).all()) and bool((t["key_len"][:nr] == shape.key_len).all())
+    assert bool((f("timestamp_delta")[:nr].view(n_b, r) == torch.arange(r, device=od.device)).all())
+    assert bool((f("val_len")[:nr] == shape.val_len).all()) and bool((f("key_len")[:nr] == shape.key_len).all())
     if nh:
         # uniform batches use exactly their header count; every record owns its own run of slots
-        assert bool((t["hkey_len"][:nh] == shape.hkey_len).all()) and bool((t["hval_len"][:nh] == shape.hval_len).all())
-        base = t["rhdr_base"][:nr].to(torch.int64).sort().values
+        assert bool((f("hkey_len")[:nh] == shape.hkey_len).all()) and bool((f("hval_len")[:nh] == shape.hval_len).all())
+        base = f("rhdr_base")[:nr].to(torch.int64).sort().values
         assert bool((base == torch.arange(nr, device=od.device) * shape.n_headers).all())
     # one batch in full against the oracle
     b = n_b // 3
