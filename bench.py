@@ -53,7 +53,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from tansu_amd import columns as C, hip, synth
+    from tansu_amd import columns as C, hip, shard
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,9 +68,7 @@ def main():
     codec = hip.Codec(local)
 
     # ---- this rank's shard: its own topic-partitions, same shape, own seed
-    shape, counts, seed = synth.config(args.workload, args.scale)
-    blob, off, n_records, n_headers = synth.make_batches(shape, counts, seed + 7919 * rank)
-    n_batches = len(counts)
+    shape, blob, off, n_records, n_headers, n_batches = shard.make_shard(args.workload, args.scale, rank)
     in_bytes = len(blob)
     d_blob, d_off = codec.to_device(blob, off)
     cols = hip.DeviceColumns(n_batches, n_records, max(n_headers, 1), dev)
@@ -86,28 +84,14 @@ def main():
         (totals.n_records, totals.n_headers, totals.n_failed)
     assert bool((cols.t["crc"][:n_batches] == cols.t["crc_computed"][:n_batches]).all())
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    def step():
+        codec.decode_dev(d_blob, in_bytes, d_off, n_batches, cols, sync=False)
 
-    for _ in range(args.warmup):
-        codec.decode_dev(d_blob, in_bytes, d_off, n_batches, cols, sync=False)
-    barrier()
-    codec.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        codec.decode_dev(d_blob, in_bytes, d_off, n_batches, cols, sync=False)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    barrier()
+    # per-kernel HIP-event timing covers the timed steps only
+    elapsed = shard.run_timed(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev),
+                              dist if world > 1 else None, dev, on_start=lambda: codec.profile(True))
     kt = codec.kernel_times()
     codec.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     if rank != 0:
         if world > 1:
@@ -130,7 +114,7 @@ def main():
         traffic = tj.get(args.workload, {}).get(name)
     result = {
         "metric": "device-resident RecordBatch v2 decode",
-        "value": total_records * args.steps / elapsed,
+        "value": shard.job_rate(n_records, world, args.steps, elapsed),
         "unit": "records/s",
         "n_gpus": world,
         "steps": args.steps,

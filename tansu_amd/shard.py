@@ -1,0 +1,64 @@
+"""Sharding and timing of a multi-process run: one process per GPU, each with its
+own topic-partitions, no exchange on the data path.
+
+Batches of different topic-partitions are independent (the reference keeps
+nothing across them: nisshi-storage/src/service/produce.rs:165-191 loops over
+partitions), so rank r of N simply works on its own shard.  The only
+communication is the barrier around the timed region and the max-reduce of the
+elapsed time; both go through torch.distributed (RCCL on GPUs, gloo on CPU).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+from . import synth
+
+
+def shard_seed(seed: int, rank: int) -> int:
+    """Seed of rank's shard: the same shape on every rank, different partitions."""
+    return seed + 7919 * rank
+
+
+def make_shard(workload: str, scale: float, rank: int):
+    """(shape, blob, batch_off, n_records, n_headers, n_batches) of one rank."""
+    shape, counts, seed = synth.config(workload, scale)
+    blob, off, n_records, n_headers = synth.make_batches(shape, counts, shard_seed(seed, rank))
+    return shape, blob, off, n_records, n_headers, len(counts)
+
+
+def run_timed(step: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None],
+              dist=None, device=None, on_start: Optional[Callable[[], None]] = None) -> float:
+    """`warmup` untimed steps, then exactly `steps` timed ones bracketed by a
+    barrier and a device sync on both sides; returns the MAX over ranks of the
+    elapsed seconds.  `dist` is torch.distributed when the job has several ranks;
+    `on_start` runs between the opening barrier and the first timed step."""
+    import torch
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    if on_start is not None:
+        on_start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def job_rate(units_per_rank: int, world: int, steps: int, elapsed: float) -> float:
+    """Whole-job throughput: what all ranks processed over the slowest rank's time."""
+    return units_per_rank * world * steps / elapsed
