@@ -1,0 +1,537 @@
+// nisshi.hpp: the record path of nisshi-sans-io as C++ types over the C ABI of
+// nisshi_hip.h.  Names, fields, argument meaning and error behaviour follow the
+// reference (paths in the tansu / nisshi reference tree):
+//
+//   record::Header                       src/record/header.rs:21-29
+//   record::Record                       src/record.rs:172-198
+//   record::deflated::{Batch, Frame}     src/record/deflated.rs:28-106
+//   record::inflated::{Batch, Frame}     src/record/inflated.rs:29-82
+//   Error                                src/lib.rs:328-366
+//
+// Conversions the reference writes as TryFrom/From are static `try_from` /
+// `from` functions here.  The ones that decode or encode records take the Codec
+// (the device context) as their first argument and run on the GPU, a whole frame
+// in one call; deflated::Batch::try_from(Bytes) only splits the 61-byte header
+// off, as in the reference, and needs no device.  Header only: link with
+// libnisshi_hip.so.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "nisshi_hip.h"
+
+namespace nisshi {
+
+// A cheaply cloneable slice of shared bytes, the role bytes::Bytes has in the reference.
+class Bytes {
+  public:
+    Bytes() : off_(0), len_(0) {}
+    explicit Bytes(std::vector<uint8_t> v)
+        : buf_(std::make_shared<const std::vector<uint8_t>>(std::move(v))), off_(0), len_(buf_->size()) {}
+    Bytes(const uint8_t *p, size_t n) : Bytes(std::vector<uint8_t>(p, p + n)) {}
+    const uint8_t *data() const { return buf_ ? buf_->data() + off_ : nullptr; }
+    size_t len() const { return len_; }
+    bool is_empty() const { return len_ == 0; }
+    uint8_t operator[](size_t i) const { return data()[i]; }
+    // Bytes::slice(off..off + n): shares the buffer
+    Bytes slice(size_t off, size_t n) const {
+        if (off > len_ || n > len_ - off) throw std::out_of_range("Bytes::slice");
+        Bytes b;
+        b.buf_ = buf_;
+        b.off_ = off_ + off;
+        b.len_ = n;
+        return b;
+    }
+    bool operator==(const Bytes &o) const { return len_ == o.len_ && (len_ == 0 || !memcmp(data(), o.data(), len_)); }
+    bool operator!=(const Bytes &o) const { return !(*this == o); }
+
+  private:
+    std::shared_ptr<const std::vector<uint8_t>> buf_;
+    size_t off_, len_;
+};
+
+// nisshi_sans_io::Error, the variants this path can produce (src/lib.rs:328-366),
+// and what the device library adds.
+struct Error {
+    enum Kind {
+        TryGet,                  // buffer under-run
+        Overflow,
+        TryFromInt,              // negative batch_length
+        UnknownCompressionType,  // detail = attributes & 7
+        Malformed,               // the reference panics on this input (codec.rs:70-74, 291-295; record.rs:260)
+        Compressed,              // a compressed batch: not decoded by the device codec
+        Capacity,
+        Device,
+        InvalidArgument,
+    } kind;
+    int detail;
+    std::string message;
+
+    static Error from_status(int status, int detail = 0) {
+        static const Kind kinds[] = {TryGet, TryGet, Overflow, TryFromInt, UnknownCompressionType,
+                                     Malformed, Compressed, Capacity, Device, InvalidArgument};
+        return Error{kinds[status >= 1 && status <= 9 ? status : 8], detail, nisshi_hip_status_str(status)};
+    }
+};
+
+// Result<T, Error>
+template <class T>
+class Result {
+  public:
+    Result(T v) : v_(std::move(v)) {}
+    Result(Error e) : v_(std::move(e)) {}
+    bool is_ok() const { return v_.index() == 0; }
+    bool is_err() const { return !is_ok(); }
+    explicit operator bool() const { return is_ok(); }
+    T &operator*() { return std::get<0>(v_); }
+    const T &operator*() const { return std::get<0>(v_); }
+    T *operator->() { return &std::get<0>(v_); }
+    const T *operator->() const { return &std::get<0>(v_); }
+    const Error &error() const { return std::get<1>(v_); }
+    // like Result::unwrap: throws on an error
+    T unwrap() && {
+        if (is_err()) throw std::runtime_error("unwrap on Err: " + error().message);
+        return std::move(std::get<0>(v_));
+    }
+
+  private:
+    std::variant<T, Error> v_;
+};
+
+// The device context.  One per thread (a context runs one call at a time).
+class Codec {
+  public:
+    explicit Codec(int device = 0) {
+        int st = nisshi_hip_ctx_create(device, &ctx_);
+        if (st) throw std::runtime_error(std::string("nisshi_hip_ctx_create: ") + nisshi_hip_status_str(st));
+    }
+    ~Codec() { nisshi_hip_ctx_destroy(ctx_); }
+    Codec(const Codec &) = delete;
+    Codec &operator=(const Codec &) = delete;
+    nisshi_hip_ctx *ctx() const { return ctx_; }
+
+  private:
+    nisshi_hip_ctx *ctx_ = nullptr;
+};
+
+namespace record {
+
+// header.rs:21-29
+struct Header {
+    std::optional<Bytes> key, value;
+    bool operator==(const Header &o) const { return key == o.key && value == o.value; }
+};
+
+// record.rs:172-198
+struct Record {
+    int32_t length = 0;
+    uint8_t attributes = 0;
+    int64_t timestamp_delta = 0;
+    int32_t offset_delta = 0;
+    std::optional<Bytes> key, value;
+    std::vector<Header> headers;
+    bool operator==(const Record &o) const {
+        return length == o.length && attributes == o.attributes && timestamp_delta == o.timestamp_delta &&
+               offset_delta == o.offset_delta && key == o.key && value == o.value && headers == o.headers;
+    }
+};
+
+namespace inflated {
+struct Batch;
+struct Frame;
+}  // namespace inflated
+
+namespace deflated {
+
+// deflated.rs:67-82
+struct Batch {
+    int64_t base_offset = 0;
+    int32_t batch_length = 0;
+    int32_t partition_leader_epoch = 0;
+    int8_t magic = 0;
+    uint32_t crc = 0;
+    int16_t attributes = 0;
+    int32_t last_offset_delta = 0;
+    int64_t base_timestamp = 0;
+    int64_t max_timestamp = 0;
+    int64_t producer_id = 0;
+    int16_t producer_epoch = 0;
+    int32_t base_sequence = 0;
+    uint32_t record_count = 0;
+    Bytes record_data;
+
+    // TryFrom<Bytes> for Batch, deflated.rs:108-213, in its order of checks.  A
+    // CRC that does not match is only logged there; it is not checked here.
+    static Result<Batch> try_from(const Bytes &encoded);
+    // From<Batch> for Bytes, deflated.rs:84-106
+    Bytes into_bytes() const;
+    // TryFrom<inflated::Batch> for Batch, deflated.rs:392-409 (uncompressed)
+    static Result<Batch> try_from(Codec &codec, const inflated::Batch &batch);
+    int64_t max_offset() const { return base_offset + int64_t(last_offset_delta); }  // deflated.rs:412-414
+
+    bool operator==(const Batch &o) const {
+        return base_offset == o.base_offset && batch_length == o.batch_length &&
+               partition_leader_epoch == o.partition_leader_epoch && magic == o.magic && crc == o.crc &&
+               attributes == o.attributes && last_offset_delta == o.last_offset_delta &&
+               base_timestamp == o.base_timestamp && max_timestamp == o.max_timestamp &&
+               producer_id == o.producer_id && producer_epoch == o.producer_epoch &&
+               base_sequence == o.base_sequence && record_count == o.record_count &&
+               record_data == o.record_data;
+    }
+};
+
+// deflated.rs:28-63
+struct Frame {
+    std::vector<Batch> batches;
+    // TryFrom<inflated::Frame> for Frame, deflated.rs:52-63: all batches in one device call
+    static Result<Frame> try_from(Codec &codec, const inflated::Frame &frame);
+    // the batches of a records blob (de.rs:1056-1093)
+    static Result<Frame> split(const Bytes &blob);
+};
+
+}  // namespace deflated
+
+namespace inflated {
+
+// inflated.rs:66-82
+struct Batch {
+    int64_t base_offset = 0;
+    int32_t batch_length = 0;
+    int32_t partition_leader_epoch = -1;
+    int8_t magic = 2;
+    uint32_t crc = 0;
+    int16_t attributes = 0;
+    int32_t last_offset_delta = 0;
+    int64_t base_timestamp = 0;
+    int64_t max_timestamp = 0;
+    int64_t producer_id = -1;
+    int16_t producer_epoch = -1;
+    int32_t base_sequence = -1;
+    std::vector<Record> records;
+
+    // TryFrom<deflated::Batch> (by value, inflated.rs:114-150: the compression bits
+    // of attributes are cleared) and TryFrom<&deflated::Batch> (inflated.rs:152-187:
+    // attributes verbatim)
+    static Result<Batch> try_from(Codec &codec, deflated::Batch &&batch);
+    static Result<Batch> try_from(Codec &codec, const deflated::Batch &batch);
+
+    bool operator==(const Batch &o) const {
+        return base_offset == o.base_offset && batch_length == o.batch_length &&
+               partition_leader_epoch == o.partition_leader_epoch && magic == o.magic && crc == o.crc &&
+               attributes == o.attributes && last_offset_delta == o.last_offset_delta &&
+               base_timestamp == o.base_timestamp && max_timestamp == o.max_timestamp &&
+               producer_id == o.producer_id && producer_epoch == o.producer_epoch &&
+               base_sequence == o.base_sequence && records == o.records;
+    }
+};
+
+// inflated.rs:29-62
+struct Frame {
+    std::vector<Batch> batches;
+    static Result<Frame> try_from(Codec &codec, deflated::Frame &&frame);
+    static Result<Frame> try_from(Codec &codec, const deflated::Frame &frame);
+};
+
+}  // namespace inflated
+
+// ---------------------------------------------------------------- implementation
+
+namespace detail {
+
+struct Cursor {  // bytes::Buf::try_get_* on a Bytes: big-endian, TryGet on under-run
+    const uint8_t *p;
+    size_t left;
+    template <class T>
+    bool get(T &out) {
+        if (left < sizeof(T)) return false;
+        uint64_t v = 0;
+        for (size_t i = 0; i < sizeof(T); i++) v = (v << 8) | p[i];
+        out = static_cast<T>(v);
+        p += sizeof(T);
+        left -= sizeof(T);
+        return true;
+    }
+};
+
+template <class T>
+inline void put_be(std::vector<uint8_t> &out, T v) {
+    for (int i = int(sizeof(T)) - 1; i >= 0; i--) out.push_back(uint8_t(uint64_t(v) >> (8 * i)));
+}
+
+// Host arrays for the columns of one call.
+struct HostColumns {
+    std::vector<int64_t> base_offset, base_timestamp, max_timestamp, producer_id, timestamp_delta;
+    std::vector<int32_t> batch_length, partition_leader_epoch, last_offset_delta, base_sequence, status;
+    std::vector<int8_t> magic;
+    std::vector<uint32_t> crc, record_count, crc_computed, data_len, rec_base, hdr_base, hdr_count;
+    std::vector<int16_t> attributes, producer_epoch;
+    std::vector<uint64_t> data_off;
+    std::vector<nisshi_record_key> rkey;
+    std::vector<nisshi_record_value> rval;
+    std::vector<uint8_t> rattributes;
+    std::vector<nisshi_header_span> hdr;
+
+    HostColumns(size_t nb, size_t nr, size_t nh) {
+        nb = nb ? nb : 1;
+        nr = nr ? nr : 1;
+        nh = nh ? nh : 1;
+        base_offset.resize(nb); base_timestamp.resize(nb); max_timestamp.resize(nb); producer_id.resize(nb);
+        batch_length.resize(nb); partition_leader_epoch.resize(nb); last_offset_delta.resize(nb);
+        base_sequence.resize(nb); status.resize(nb); magic.resize(nb); crc.resize(nb); record_count.resize(nb);
+        crc_computed.resize(nb); data_len.resize(nb); rec_base.resize(nb); hdr_base.resize(nb);
+        hdr_count.resize(nb); attributes.resize(nb); producer_epoch.resize(nb); data_off.resize(nb);
+        rkey.resize(nr); rval.resize(nr); timestamp_delta.resize(nr); rattributes.resize(nr);
+        hdr.resize(nh);
+    }
+    nisshi_columns c() {
+        nisshi_columns c;
+        c.base_offset = base_offset.data(); c.batch_length = batch_length.data();
+        c.partition_leader_epoch = partition_leader_epoch.data(); c.magic = magic.data(); c.crc = crc.data();
+        c.attributes = attributes.data(); c.last_offset_delta = last_offset_delta.data();
+        c.base_timestamp = base_timestamp.data(); c.max_timestamp = max_timestamp.data();
+        c.producer_id = producer_id.data(); c.producer_epoch = producer_epoch.data();
+        c.base_sequence = base_sequence.data(); c.record_count = record_count.data();
+        c.crc_computed = crc_computed.data(); c.data_off = data_off.data(); c.data_len = data_len.data();
+        c.rec_base = rec_base.data(); c.hdr_base = hdr_base.data(); c.hdr_count = hdr_count.data();
+        c.status = status.data(); c.rkey = rkey.data(); c.rval = rval.data();
+        c.timestamp_delta = timestamp_delta.data(); c.rattributes = rattributes.data(); c.hdr = hdr.data();
+        return c;
+    }
+};
+
+inline std::optional<Bytes> span(const Bytes &data, uint32_t off, int32_t len) {
+    if (len < 0) return std::nullopt;
+    return data.slice(off, size_t(len));
+}
+
+// inflated::Frame::try_from over a whole frame: one blob, one device call
+inline Result<inflated::Frame> inflate(Codec &codec, const deflated::Frame &frame, bool by_value) {
+    size_t nb = frame.batches.size();
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> off(nb + 1, 0);
+    uint64_t rec_cap = 0;
+    for (size_t b = 0; b < nb; b++) {
+        Bytes e = frame.batches[b].into_bytes();
+        blob.insert(blob.end(), e.data(), e.data() + e.len());
+        off[b + 1] = blob.size();
+        rec_cap += frame.batches[b].record_count;
+    }
+    // a record is at least seven bytes, a header at least two
+    if (rec_cap > blob.size() / 7 + 1) rec_cap = blob.size() / 7 + 1;
+    uint64_t hdr_cap = blob.size() / 2 + 4096 * nb + 1;
+    HostColumns cols(nb, rec_cap, hdr_cap);
+    nisshi_columns c = cols.c();
+    nisshi_totals totals{};
+    int st = nisshi_hip_decode(codec.ctx(), blob.data(), blob.size(), off.data(), uint32_t(nb), by_value ? 1 : 0,
+                               &c, rec_cap, hdr_cap, &totals);
+    if (st) return Error::from_status(st);
+    inflated::Frame out;
+    out.batches.reserve(nb);
+    for (size_t b = 0; b < nb; b++) {
+        const deflated::Batch &d = frame.batches[b];
+        // the first failing batch is the frame's error (collect::<Result<Vec<_>>>)
+        if (cols.status[b]) return Error::from_status(cols.status[b], d.attributes & 7);
+        inflated::Batch ib;
+        ib.base_offset = cols.base_offset[b];
+        ib.batch_length = cols.batch_length[b];
+        ib.partition_leader_epoch = cols.partition_leader_epoch[b];
+        ib.magic = cols.magic[b];
+        ib.crc = cols.crc[b];
+        ib.attributes = cols.attributes[b];
+        ib.last_offset_delta = cols.last_offset_delta[b];
+        ib.base_timestamp = cols.base_timestamp[b];
+        ib.max_timestamp = cols.max_timestamp[b];
+        ib.producer_id = cols.producer_id[b];
+        ib.producer_epoch = cols.producer_epoch[b];
+        ib.base_sequence = cols.base_sequence[b];
+        ib.records.reserve(cols.record_count[b]);
+        for (uint32_t r = cols.rec_base[b]; r < cols.rec_base[b] + cols.record_count[b]; r++) {
+            Record rec;
+            rec.length = cols.rkey[r].length;
+            rec.attributes = cols.rattributes[r];
+            rec.timestamp_delta = cols.timestamp_delta[r];
+            rec.offset_delta = cols.rkey[r].offset_delta;
+            rec.key = span(d.record_data, cols.rkey[r].key_off, cols.rkey[r].key_len);
+            rec.value = span(d.record_data, cols.rval[r].val_off, cols.rval[r].val_len);
+            rec.headers.reserve(size_t(cols.rval[r].hdr_count));
+            for (uint32_t h = cols.rval[r].hdr_base; h < cols.rval[r].hdr_base + uint32_t(cols.rval[r].hdr_count); h++)
+                rec.headers.push_back(Header{span(d.record_data, cols.hdr[h].key_off, cols.hdr[h].key_len),
+                                             span(d.record_data, cols.hdr[h].val_off, cols.hdr[h].val_len)});
+            ib.records.push_back(std::move(rec));
+        }
+        out.batches.push_back(std::move(ib));
+    }
+    return out;
+}
+
+// deflated::Frame::try_from(inflated::Frame): columns and one payload, one device call
+inline Result<deflated::Frame> deflate(Codec &codec, const inflated::Frame &frame) {
+    size_t nb = frame.batches.size(), nr = 0, nh = 0;
+    for (const auto &b : frame.batches) {
+        nr += b.records.size();
+        for (const auto &r : b.records) nh += r.headers.size();
+    }
+    HostColumns cols(nb, nr, nh);
+    std::vector<uint8_t> payload;
+    std::vector<uint64_t> src_off(nb ? nb : 1, 0);
+    size_t r = 0, h = 0;
+    for (size_t b = 0; b < nb; b++) {
+        const inflated::Batch &ib = frame.batches[b];
+        cols.base_offset[b] = ib.base_offset;
+        cols.batch_length[b] = ib.batch_length;
+        cols.partition_leader_epoch[b] = ib.partition_leader_epoch;
+        cols.magic[b] = ib.magic;
+        cols.crc[b] = ib.crc;
+        cols.attributes[b] = ib.attributes;
+        cols.last_offset_delta[b] = ib.last_offset_delta;
+        cols.base_timestamp[b] = ib.base_timestamp;
+        cols.max_timestamp[b] = ib.max_timestamp;
+        cols.producer_id[b] = ib.producer_id;
+        cols.producer_epoch[b] = ib.producer_epoch;
+        cols.base_sequence[b] = ib.base_sequence;
+        cols.record_count[b] = uint32_t(ib.records.size());
+        cols.rec_base[b] = uint32_t(r);
+        cols.hdr_base[b] = uint32_t(h);
+        cols.status[b] = NISSHI_OK;
+        size_t base = payload.size();
+        src_off[b] = base;
+        size_t h0 = h;
+        auto put = [&](const std::optional<Bytes> &s, uint32_t &off, int32_t &len) {
+            off = uint32_t(payload.size() - base);
+            len = s ? int32_t(s->len()) : -1;
+            if (s) payload.insert(payload.end(), s->data(), s->data() + s->len());
+        };
+        for (const Record &rec : ib.records) {
+            cols.rkey[r].length = rec.length;
+            cols.rkey[r].offset_delta = rec.offset_delta;
+            cols.rattributes[r] = rec.attributes;
+            cols.timestamp_delta[r] = rec.timestamp_delta;
+            put(rec.key, cols.rkey[r].key_off, cols.rkey[r].key_len);
+            put(rec.value, cols.rval[r].val_off, cols.rval[r].val_len);
+            cols.rval[r].hdr_base = uint32_t(h);
+            cols.rval[r].hdr_count = int32_t(rec.headers.size());
+            for (const Header &hd : rec.headers) {
+                put(hd.key, cols.hdr[h].key_off, cols.hdr[h].key_len);
+                put(hd.value, cols.hdr[h].val_off, cols.hdr[h].val_len);
+                h++;
+            }
+            r++;
+        }
+        cols.hdr_count[b] = uint32_t(h - h0);
+        cols.data_off[b] = base;
+        cols.data_len[b] = uint32_t(payload.size() - base);
+    }
+    uint64_t out_cap = 2 * payload.size() + 128 * nb + 64 * nr + 1024;
+    std::vector<uint8_t> out(out_cap);
+    std::vector<uint64_t> out_off(nb + 1, 0);
+    nisshi_columns c = cols.c();
+    nisshi_totals totals{};
+    int st = nisshi_hip_encode(codec.ctx(), &c, uint32_t(nb), nr, nh, payload.data(), payload.size(),
+                               src_off.data(), out.data(), out_cap, out_off.data(), &totals);
+    if (st) return Error::from_status(st);
+    Bytes all(out.data(), size_t(totals.out_bytes));
+    deflated::Frame f;
+    f.batches.reserve(nb);
+    for (size_t b = 0; b < nb; b++) {
+        auto d = deflated::Batch::try_from(all.slice(size_t(out_off[b]), size_t(out_off[b + 1] - out_off[b])));
+        if (d.is_err()) return d.error();
+        f.batches.push_back(*d);
+    }
+    return f;
+}
+
+}  // namespace detail
+
+inline Result<deflated::Batch> deflated::Batch::try_from(const Bytes &encoded) {
+    detail::Cursor cur{encoded.data(), encoded.len()};
+    Batch b;
+    if (!cur.get(b.base_offset) || !cur.get(b.batch_length) || !cur.get(b.partition_leader_epoch) ||
+        !cur.get(b.magic) || !cur.get(b.crc))
+        return Error::from_status(NISSHI_TRY_GET);
+    if (b.batch_length < 0) return Error::from_status(NISSHI_TRY_FROM_INT);
+    // batch_length - 4 - 1 - 4 bytes are covered by the CRC and must be present
+    if (b.batch_length < 9 || size_t(b.batch_length) - 9 > cur.left) return Error::from_status(NISSHI_OVERFLOW);
+    if (!cur.get(b.attributes) || !cur.get(b.last_offset_delta) || !cur.get(b.base_timestamp) ||
+        !cur.get(b.max_timestamp) || !cur.get(b.producer_id) || !cur.get(b.producer_epoch) ||
+        !cur.get(b.base_sequence) || !cur.get(b.record_count))
+        return Error::from_status(NISSHI_TRY_GET);
+    if (b.batch_length < 49 || size_t(b.batch_length) - 49 > cur.left) return Error::from_status(NISSHI_OVERFLOW);
+    b.record_data = encoded.slice(encoded.len() - cur.left, size_t(b.batch_length) - 49);
+    return b;
+}
+
+inline Bytes deflated::Batch::into_bytes() const {
+    std::vector<uint8_t> out;
+    out.reserve(61 + record_data.len());
+    detail::put_be(out, base_offset);
+    detail::put_be(out, batch_length);
+    detail::put_be(out, partition_leader_epoch);
+    detail::put_be(out, magic);
+    detail::put_be(out, crc);
+    detail::put_be(out, attributes);
+    detail::put_be(out, last_offset_delta);
+    detail::put_be(out, base_timestamp);
+    detail::put_be(out, max_timestamp);
+    detail::put_be(out, producer_id);
+    detail::put_be(out, producer_epoch);
+    detail::put_be(out, base_sequence);
+    detail::put_be(out, record_count);
+    out.insert(out.end(), record_data.data(), record_data.data() + record_data.len());
+    return Bytes(std::move(out));
+}
+
+inline Result<deflated::Frame> deflated::Frame::split(const Bytes &blob) {
+    std::vector<uint64_t> off(blob.len() / 61 + 2);
+    uint64_t n = 0;
+    int st = nisshi_frame_split(blob.data(), blob.len(), off.data(), off.size(), &n);
+    if (st) return Error::from_status(st);
+    Frame f;
+    for (uint64_t b = 0; b < n; b++) {
+        auto d = Batch::try_from(blob.slice(size_t(off[b]), size_t(off[b + 1] - off[b])));
+        if (d.is_err()) return d.error();
+        f.batches.push_back(*d);
+    }
+    return f;
+}
+
+inline Result<inflated::Frame> inflated::Frame::try_from(Codec &codec, deflated::Frame &&frame) {
+    return detail::inflate(codec, frame, true);
+}
+inline Result<inflated::Frame> inflated::Frame::try_from(Codec &codec, const deflated::Frame &frame) {
+    return detail::inflate(codec, frame, false);
+}
+inline Result<inflated::Batch> inflated::Batch::try_from(Codec &codec, deflated::Batch &&batch) {
+    deflated::Frame f;
+    f.batches.push_back(std::move(batch));
+    auto r = detail::inflate(codec, f, true);
+    if (r.is_err()) return r.error();
+    return std::move(r->batches[0]);
+}
+inline Result<inflated::Batch> inflated::Batch::try_from(Codec &codec, const deflated::Batch &batch) {
+    deflated::Frame f;
+    f.batches.push_back(batch);
+    auto r = detail::inflate(codec, f, false);
+    if (r.is_err()) return r.error();
+    return std::move(r->batches[0]);
+}
+inline Result<deflated::Frame> deflated::Frame::try_from(Codec &codec, const inflated::Frame &frame) {
+    return detail::deflate(codec, frame);
+}
+inline Result<deflated::Batch> deflated::Batch::try_from(Codec &codec, const inflated::Batch &batch) {
+    inflated::Frame f;
+    f.batches.push_back(batch);
+    auto r = detail::deflate(codec, f);
+    if (r.is_err()) return r.error();
+    return std::move(r->batches[0]);
+}
+
+}  // namespace record
+}  // namespace nisshi
