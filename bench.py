@@ -36,7 +36,7 @@ KERNEL_BYTES = {
     "headers_kernel": lambda s: 16 * s["n_headers"],
     "batch_header_kernel": lambda s: 64 * s["n_batches"],
     "decode_fused_kernel": lambda s: s["in_bytes"] + 41 * s["n_records"] + 16 * s["n_headers"],
-    "walk_global_kernel": lambda s: s["in_bytes"] + 41 * s["n_records"] + 16 * s["n_headers"],
+    "slow_walk_kernel": lambda s: s["in_bytes"] + 41 * s["n_records"] + 16 * s["n_headers"],
 }
 
 

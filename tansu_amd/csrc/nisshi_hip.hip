@@ -5,12 +5,11 @@
 // Decode pipeline (all on one stream):
 //   batch_header_kernel   one lane per batch: the 61-byte header, its checks, the record_data span
 //   scan_batches_kernel   exclusive scans over batches: record slots, CRC work items
-//   crc_chunks_kernel     large batches only: one wave per 64 KiB, CRC-32C by sparse folding
-//   crc_finish_kernel     combines the chunks of those batches
+//   crc_chunks_kernel     batches of 512 KiB and more only: one wave per 64 KiB, CRC-32C by sparse folding
 //   decode_fused_kernel   one wave per batch: CRC-32C streamed just ahead of the record walk;
-//                         record starts by speculation, one lane per record, header spans inline
-//   exact_kernel          sequential field walk for batches whose lengths disagree with their fields
-//   finish_kernel         totals
+//                         record starts by speculation, records matched against a learnt shape
+//   slow_walk_kernel      what the streamed walk left: large batches and unusual records from
+//                         global memory, the sequential walk for exact error outcomes, the totals
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -137,8 +136,7 @@ __global__ void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_o
 
 // ------------------------------------------------------------ batch-level scans
 
-// Exclusive scans over batches by one workgroup.  Batch counts are small next to
-// record counts, so a single group walking 1024 entries at a time is enough.
+// Exclusive scan of one value a thread over a workgroup (the encoder's scans).
 __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t &total) {
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t inc = v;
@@ -161,75 +159,130 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint3
     return offset + inc - v;
 }
 
-__global__ void scan_batches_kernel(uint32_t n, nisshi_columns c, Work w) {
-    __shared__ uint32_t lds[16];
-    uint32_t rec_run = 0, chunk_run = 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x) {
-        uint32_t b = base + threadIdx.x;
-        uint32_t cnt = b < n ? w.alloc_count[b] : 0;
-        uint32_t chk = b < n ? w.n_chunks[b] : 0;
-        uint32_t tot;
-        uint32_t e = block_exclusive_scan(cnt, lds, tot);
-        if (b < n) c.rec_base[b] = rec_run + e;
-        rec_run += tot;
-        e = block_exclusive_scan(chk, lds, tot);
-        if (b < n) w.chunk_base[b] = chunk_run + e;
-        chunk_run += tot;
+// Exclusive scans over batches by one workgroup: record slots and CRC work items
+// together, as the two halves of one 64-bit sum.  A thread takes kScanItems
+// consecutive batches, so 8192 batches are one pass.  Only batches of at least
+// min_chunks chunks have CRC work items (the others get their CRC elsewhere).
+constexpr int kScanItems = 8;
+
+__global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_columns c, Work w,
+                                                            uint32_t min_chunks) {
+    __shared__ uint64_t wave_sum[16];
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t run = 0;  // records in the low half, work items in the high half
+    for (uint32_t base = 0; base < n; base += blockDim.x * kScanItems) {
+        uint32_t b0 = base + threadIdx.x * kScanItems;
+        uint64_t v[kScanItems], mine = 0;
+        // 16-byte loads: the workspace arrays are padded past n, so whole groups can
+        // be read (entries past n are masked); a dword a lane would cost four times
+        // the load instructions on the one CU this runs on
+        uint32_t cnt[kScanItems] = {}, chk[kScanItems] = {};
+        if (b0 < n) {
+#pragma unroll
+            for (int i = 0; i < kScanItems; i += 4) {
+                uint4 a = *reinterpret_cast<const uint4 *>(w.alloc_count + b0 + i);
+                uint4 k = *reinterpret_cast<const uint4 *>(w.n_chunks + b0 + i);
+                cnt[i] = a.x, cnt[i + 1] = a.y, cnt[i + 2] = a.z, cnt[i + 3] = a.w;
+                chk[i] = k.x, chk[i + 1] = k.y, chk[i + 2] = k.z, chk[i + 3] = k.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kScanItems; i++) {
+            bool in = b0 + i < n;
+            uint32_t items = in && chk[i] >= min_chunks ? chk[i] : 0;
+            v[i] = ((uint64_t)items << 32) | (in ? cnt[i] : 0u);
+            mine += v[i];
+        }
+        uint64_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_sum[wid] = inc;
+        __syncthreads();
+        uint64_t before = 0, total = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) {
+            uint64_t s = wave_sum[i];
+            if (i < wid) before += s;
+            total += s;
+        }
+        __syncthreads();
+        uint64_t e = run + before + inc - mine;
+        uint32_t rb[kScanItems], cb[kScanItems];
+#pragma unroll
+        for (int i = 0; i < kScanItems; i++) {
+            rb[i] = (uint32_t)e;
+            cb[i] = (uint32_t)(e >> 32);
+            e += v[i];
+        }
+        if (b0 + kScanItems <= n && (reinterpret_cast<uintptr_t>(c.rec_base) & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < kScanItems; i += 4)
+                *reinterpret_cast<uint4 *>(c.rec_base + b0 + i) = make_uint4(rb[i], rb[i + 1], rb[i + 2], rb[i + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kScanItems; i++)
+                if (b0 + i < n) c.rec_base[b0 + i] = rb[i];
+        }
+        if (b0 < n) {  // chunk_base is a workspace array, padded like the others
+#pragma unroll
+            for (int i = 0; i < kScanItems; i += 4)
+                *reinterpret_cast<uint4 *>(w.chunk_base + b0 + i) = make_uint4(cb[i], cb[i + 1], cb[i + 2], cb[i + 3]);
+        }
+        run += total;
     }
     if (threadIdx.x == 0) {
-        w.chunk_base[n] = chunk_run;
-        w.totals[0] = rec_run;
-        w.totals[5] = chunk_run;
+        w.chunk_base[n] = (uint32_t)(run >> 32);
+        w.totals[0] = (uint32_t)run;
+        w.totals[5] = run >> 32;
     }
 }
 
 // ------------------------------------------------------------ CRC-32C
 
-// One wave per work item: item -> (batch, chunk) by binary search in the scan.
+// One wave per work item, as many passes as the grid needs: item -> (batch, chunk)
+// by binary search in the scan.
 __global__ void crc_chunks_kernel(const uint8_t *blob, const uint64_t *batch_off,
                                   const int32_t *batch_length, uint32_t n, uint32_t *crc_out,
-                                  Work w, const CrcTables *t, uint32_t min_chunks) {
-    uint32_t item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+                                  Work w, const CrcTables *t) {
     int lane = threadIdx.x & 63;
     uint32_t total = w.chunk_base[n];
-    if (item >= total) return;
-    uint32_t lo_b = 0, hi_b = n;  // largest b with chunk_base[b] <= item
-    while (hi_b - lo_b > 1) {
-        uint32_t mid = (lo_b + hi_b) >> 1;
-        if (w.chunk_base[mid] <= item) lo_b = mid; else hi_b = mid;
-    }
-    uint32_t b = lo_b;
-    uint32_t chunk = item - w.chunk_base[b];
-    uint32_t chunks = w.n_chunks[b];
-    if (chunks < min_chunks) return;  // small batches get their CRC from the fused walk
-    uint64_t lo = batch_off[b] + 21;
-    uint64_t hi = lo + (uint64_t)batch_length[b] - 9;
-    uint64_t grid = lo & ~uint64_t(15);
-    uint32_t rows = (uint32_t)((hi - grid + kRowBytes - 1) / kRowBytes);
-    uint32_t row0 = chunk * kChunkRows;
-    uint32_t row1 = row0 + kChunkRows < rows ? row0 + kChunkRows : rows;
-    uint64_t first4 = chunk == 0 ? lo : (uint64_t(1) << 62);
-    uint32_t r = crc_rows(blob, grid, lo, hi, first4, row0, row1, lane, t);
-    if (chunk + 1 == chunks) {
-        // the last row was zero padded up to its end: divide the padding out
-        uint64_t pad = grid + (uint64_t)rows * kRowBytes - hi;
-        if (hi == lo) pad = 0;
-        r = gf_mulmod(r, t->inv8[pad]);
-    }
-    if (lane == 0) {
-        w.partial[item] = r;
-        if (chunks == 1) crc_out[b] = hi == lo ? 0u : ~r;
+    for (uint32_t item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); item < total;
+         item += gridDim.x * kWavesPerBlock) {
+        uint32_t lo_b = 0, hi_b = n;  // largest b with chunk_base[b] <= item and work items of its own
+        while (hi_b - lo_b > 1) {
+            uint32_t mid = (lo_b + hi_b) >> 1;
+            if (w.chunk_base[mid] <= item) lo_b = mid; else hi_b = mid;
+        }
+        uint32_t b = lo_b;
+        uint32_t chunk = item - w.chunk_base[b];
+        uint32_t chunks = w.n_chunks[b];
+        uint64_t lo = batch_off[b] + 21;
+        uint64_t hi = lo + (uint64_t)batch_length[b] - 9;
+        uint64_t grid = lo & ~uint64_t(15);
+        uint32_t rows = (uint32_t)((hi - grid + kRowBytes - 1) / kRowBytes);
+        uint32_t row0 = chunk * kChunkRows;
+        uint32_t row1 = row0 + kChunkRows < rows ? row0 + kChunkRows : rows;
+        uint64_t first4 = chunk == 0 ? lo : (uint64_t(1) << 62);
+        uint32_t r = crc_rows(blob, grid, lo, hi, first4, row0, row1, lane, t);
+        if (chunk + 1 == chunks) {
+            // the last row was zero padded up to its end: divide the padding out
+            uint64_t pad = grid + (uint64_t)rows * kRowBytes - hi;
+            if (hi == lo) pad = 0;
+            r = gf_mulmod(r, t->inv8[pad]);
+        }
+        if (lane == 0) {
+            w.partial[item] = r;
+            if (chunks == 1) crc_out[b] = hi == lo ? 0u : ~r;
+        }
     }
 }
 
-// Batches of more than one chunk: R = sum over chunks of R_c * x^(8 * bytes after chunk c).
-__global__ void crc_finish_kernel(const uint64_t *batch_off, const int32_t *batch_length,
-                                  uint32_t n, uint32_t *crc_out, Work w, const CrcTables *t,
-                                  uint32_t min_chunks) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n) return;
-    uint32_t chunks = w.n_chunks[b];
-    if (chunks < 2 || chunks < min_chunks) return;
+// The CRC of a batch of more than one chunk from its chunks' residues:
+// R = sum over chunks of R_c * x^(8 * bytes after chunk c).
+__device__ inline uint32_t crc_combine(const uint64_t *batch_off, const int32_t *batch_length,
+                                       uint32_t b, uint32_t chunks, const Work &w, const CrcTables *t) {
     uint64_t lo = batch_off[b] + 21;
     uint64_t hi = lo + (uint64_t)batch_length[b] - 9;
     uint64_t grid = lo & ~uint64_t(15);
@@ -238,7 +291,16 @@ __global__ void crc_finish_kernel(const uint64_t *batch_off, const int32_t *batc
     uint32_t r = part[0];
     for (uint32_t k = 1; k + 1 < chunks; k++) r = gf_mulmod(r, t->chunk_weight) ^ part[k];
     r = gf_mulmod(r, gf_xpow8(t, last_bytes)) ^ part[chunks - 1];
-    crc_out[b] = ~r;
+    return ~r;
+}
+
+__global__ void crc_finish_kernel(const uint64_t *batch_off, const int32_t *batch_length,
+                                  uint32_t n, uint32_t *crc_out, Work w, const CrcTables *t) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    uint32_t chunks = w.n_chunks[b];
+    if (chunks < 2) return;
+    crc_out[b] = crc_combine(batch_off, batch_length, b, chunks, w, t);
 }
 
 // ------------------------------------------------------------ record walk
@@ -343,8 +405,8 @@ struct HeaderRuns {
 
 // How a wave's walk of a batch ended.
 constexpr int kWalkDone = 0;
-constexpr int kWalkExact = 1;   // a record that does not decode, or whose length disagrees: exact_kernel
-constexpr int kWalkGlobal = 2;  // records the streamed walk cannot express: walk_global_kernel
+constexpr int kWalkExact = 1;   // a record that does not decode, or whose length disagrees: exact_walk
+constexpr int kWalkGlobal = 2;  // records the streamed walk cannot express: walk_global
 
 // ---- the walk from global memory
 //
@@ -841,7 +903,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
 // One wave per batch: CRC-32C of the batch streamed just ahead of the record
 // walk through an LDS ring, so the batch is read from HBM once.  Batches of
 // kBigChunks chunks or more get their CRC from crc_chunks_kernel instead (one
-// wave cannot stream them fast enough) and their records from walk_global_kernel.
+// wave cannot stream them fast enough) and their records from slow_walk_kernel.
 constexpr uint32_t kBigChunks = 8;
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_fused_kernel(const uint8_t *blob,
@@ -882,46 +944,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (lane == 0) c.crc_computed[b] = v;
 }
 
-// One wave per batch the streamed walk left: batches of kBigChunks chunks or
-// more from their start, flagged ones from where the streamed walk stopped.
-__global__ __launch_bounds__(64) void walk_global_kernel(const uint8_t *blob, uint32_t n,
-                                                         nisshi_columns c, Work w, uint64_t rec_cap,
-                                                         uint64_t hdr_cap) {
-    uint32_t b = blockIdx.x;
-    int lane = threadIdx.x;
-    if (b >= n) return;
-    uint32_t flags = uni(w.flags[b]);
-    if (uni(c.status[b]) != NISSHI_OK || (flags & kFlagExact)) return;
-    bool big = uni(w.n_chunks[b]) >= kBigChunks;
-    if (!big && !(flags & kFlagGlobal)) return;
-    HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
-    uint32_t k = 0, pos = 0;
-    if (flags & kFlagGlobal) {
-        k = uni(w.resume_k[b]);
-        pos = uni(w.resume_pos[b]);
-        runs.total = uni(c.hdr_count[b]);
-        runs.first_slot = uni(c.hdr_base[b]);
-    } else if ((uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
-        if (lane == 0) c.status[b] = NISSHI_CAPACITY;
-        return;
-    }
-    int st = walk_global(blob, b, c, runs, k, pos, lane);
-    if (lane == 0) {
-        c.hdr_count[b] = runs.total;
-        c.hdr_base[b] = runs.first_slot;
-        if (st != kWalkDone) w.flags[b] |= kFlagExact;
-    }
-}
-
 // One lane per flagged batch: Record::decode in sequence, exactly as
 // Vec<Record>::try_from(deflated::Batch) does (deflated.rs:431-442).  The first
 // error ends the batch with its status; records are stored only while the batch
 // has slots (a batch whose count cannot fit has none and only gets its status).
-__global__ void exact_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, Work w,
-                             uint64_t rec_cap, uint64_t hdr_cap) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n) return;
-    if (!(w.flags[b] & kFlagExact) || c.status[b] != NISSHI_OK) return;
+__device__ __forceinline__ void exact_walk(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
+                                        const Work &w, uint64_t rec_cap, uint64_t hdr_cap) {
     uint32_t count = c.record_count[b];
     uint32_t slots = w.alloc_count[b];
     uint32_t rbase = c.rec_base[b];
@@ -971,15 +999,51 @@ __global__ void exact_kernel(const uint8_t *blob, uint32_t n, nisshi_columns c, 
     c.hdr_base[b] = first_slot;
 }
 
-// Totals over batches once every status is final.
-__global__ void finish_kernel(uint32_t n, nisshi_columns c, Work w) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    bool failed = b < n && c.status[b] != NISSHI_OK;
-    bool exact = b < n && (w.flags[b] & kFlagExact);
-    uint64_t fm = __ballot(failed), em = __ballot(exact);
-    if ((threadIdx.x & 63) == 0) {
-        if (fm) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), (unsigned long long)__popcll(fm));
-        if (em) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), (unsigned long long)__popcll(em));
+// Everything the streamed walk left, one wave per batch: the CRC of batches of
+// kBigChunks chunks or more from their chunks' residues and their record walk
+// from global memory; flagged batches from where the streamed walk stopped; the
+// sequential walk for batches that need the reference's exact outcome; and the
+// batch's share of the totals, its status being final here.
+__global__ __launch_bounds__(64) void slow_walk_kernel(const uint8_t *blob, const uint64_t *batch_off,
+                                                       uint32_t n, nisshi_columns c, Work w,
+                                                       uint64_t rec_cap, uint64_t hdr_cap,
+                                                       const CrcTables *t) {
+    uint32_t b = blockIdx.x;
+    int lane = threadIdx.x;
+    if (b >= n) return;
+    uint32_t flags = uni(w.flags[b]);
+    uint32_t chunks = uni(w.n_chunks[b]);
+    bool big = chunks >= kBigChunks;
+    // the usual batch was done by the streamed walk: nothing left
+    if (!big && flags == 0 && uni(c.status[b]) == NISSHI_OK) return;
+    if (big && lane == 0) c.crc_computed[b] = crc_combine(batch_off, c.batch_length, b, chunks, w, t);
+    bool ok = uni(c.status[b]) == NISSHI_OK;
+    if (ok && !(flags & kFlagExact) && (big || (flags & kFlagGlobal))) {
+        HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
+        uint32_t k = 0, pos = 0;
+        bool fits = true;
+        if (flags & kFlagGlobal) {
+            k = uni(w.resume_k[b]);
+            pos = uni(w.resume_pos[b]);
+            runs.total = uni(c.hdr_count[b]);
+            runs.first_slot = uni(c.hdr_base[b]);
+        } else if ((uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
+            if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+            fits = false;
+        }
+        if (fits) {
+            int st = walk_global(blob, b, c, runs, k, pos, lane);
+            if (lane == 0) {
+                c.hdr_count[b] = runs.total;
+                c.hdr_base[b] = runs.first_slot;
+            }
+            if (st != kWalkDone) flags |= kFlagExact;
+        }
+    }
+    if (lane == 0) {
+        if (ok && (flags & kFlagExact) && c.status[b] == NISSHI_OK) exact_walk(blob, b, c, w, rec_cap, hdr_cap);
+        if (c.status[b] != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+        if (flags & kFlagExact) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
     }
 }
 
