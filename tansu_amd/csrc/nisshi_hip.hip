@@ -355,7 +355,7 @@ constexpr uint32_t kHdrRunMax = 4096;
 struct HeaderRuns {
     unsigned long long *cursor;
     uint64_t cap;
-    uint64_t run_pos, run_end;  // slots in hand
+    uint32_t run_pos, run_end;   // slots in hand (slot numbers fit 32 bits: the columns hold them so)
     uint32_t total, first_slot;  // of the batch so far
 
     // Slots for one round of `m` records, `left` records of the batch following
@@ -363,7 +363,7 @@ struct HeaderRuns {
     // false when the header columns are full.  When the round's slots are one
     // piece, `piece` is its first slot.
     __device__ __forceinline__ bool take(uint32_t hc, uint32_t m, uint32_t left, int lane,
-                                         uint32_t &slot, uint64_t &piece, bool &one_piece) {
+                                         uint32_t &slot, uint32_t &piece, bool &one_piece) {
         // equal header counts in every record (the usual case) need no scan
         uint32_t hc0 = uni(hc);
         bool live = (uint32_t)lane < m;
@@ -371,7 +371,7 @@ struct HeaderRuns {
                                                        : wave_inclusive_scan(hc, lane);
         uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         // records whose headers fit in the run in hand use it, the rest a new run
-        uint64_t room = run_end - run_pos;
+        uint32_t room = run_end - run_pos;
         bool fits = inc <= room;
         uint64_t fit_mask = __ballot(fits);
         uint32_t n_fit = fit_mask == ~0ull ? 64 : (uint32_t)__ffsll((long long)~fit_mask) - 1;
@@ -385,14 +385,14 @@ struct HeaderRuns {
             grab = rest + (uint32_t)(ahead < kHdrRunMax ? ahead : kHdrRunMax);
             if (lane == 0) new_base = atomicAdd(cursor, (unsigned long long)grab);
             new_base = uni64(new_base);
-            if (new_base + grab > cap) return false;
+            if (new_base + grab > cap || new_base + grab > 0xffffffffull) return false;
         }
         one_piece = rest == 0 || used_old == 0;
-        piece = rest ? new_base : run_pos;
-        slot = (uint32_t)(fits ? run_pos : new_base) + inc - hc - (fits ? 0 : used_old);
+        piece = rest ? (uint32_t)new_base : run_pos;
+        slot = (fits ? run_pos : (uint32_t)new_base) + inc - hc - (fits ? 0 : used_old);
         if (rest) {
-            run_pos = new_base + rest;
-            run_end = new_base + grab;
+            run_pos = (uint32_t)new_base + rest;
+            run_end = (uint32_t)new_base + grab;
         } else {
             run_pos += sum;
         }
@@ -400,6 +400,24 @@ struct HeaderRuns {
             first_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, __ffsll((long long)__ballot(hc > 0)) - 1);
         total += sum;
         return true;
+    }
+
+    // The same for m records of hc headers each (hc > 0, uniform): when the run in
+    // hand holds them all, which it does but for a few rounds of a batch, the slots
+    // follow from the lane number.
+    __device__ __forceinline__ bool take_uniform(uint32_t hc, uint32_t m, uint32_t left, int lane,
+                                                 uint32_t &slot, uint32_t &piece, bool &one_piece) {
+        uint32_t sum = m * hc;
+        if (sum <= run_end - run_pos) {
+            slot = run_pos + (uint32_t)lane * hc;
+            piece = run_pos;
+            one_piece = true;
+            if (total == 0) first_slot = run_pos;
+            run_pos += sum;
+            total += sum;
+            return true;
+        }
+        return take((uint32_t)lane < m ? hc : 0u, m, left, lane, slot, piece, one_piece);
     }
 };
 
@@ -506,7 +524,7 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
         uint32_t hc = ok ? (uint32_t)f.hdr_count : 0;
         uint32_t slot = 0;
         if (__any(hc != 0)) {
-            uint64_t piece;
+            uint32_t piece;
             bool one_piece;
             if (!runs.take(hc, m, count - k - m, lane, slot, piece, one_piece)) {
                 if (lane == 0) c.status[b] = NISSHI_CAPACITY;
@@ -547,7 +565,7 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
 // fields sit at known offsets.  The wave learns the shape of a record as a list
 // of masked 32-bit compares (kept in LDS, as are the header spans relative to the
 // record start) and tests the records that follow against it, 64 at a time.
-constexpr uint32_t kShapeChecks = 24;  // even
+constexpr uint32_t kShapeChecks = 24;  // a multiple of four
 constexpr uint32_t kShapeHdrs = 16;
 constexpr uint32_t kShapeWords = (kShapeChecks + kShapeHdrs + 3) * 4;  // and the learnt scalars
 
@@ -651,14 +669,14 @@ __device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView ring, uint32
     }
     if (noted < kShapeChecks) tab[noted] = u32x4{cur_off, cur_mask, cur_pat, 0};
     noted++;
-    // pad to an even number with a compare that always holds
-    if (noted < kShapeChecks && (noted & 1)) tab[noted] = u32x4{0, 0, 0, 0};
+    // pad to a multiple of four with compares that always hold
+    for (uint32_t i = noted; i < ((noted + 3) & ~3u) && i < kShapeChecks; i++) tab[i] = u32x4{0, 0, 0, 0};
     int st = kWalkDone;
     // a varint too wide for the fast decode may be valid: the slower walk decides
     if (wide || hc > kShapeHdrs || noted > kShapeChecks) st = kWalkGlobal;
     // the fields must end exactly where the length said
     else if (bad || p != size) st = kWalkExact;
-    out[0] = u32x4{(noted + 1) & ~1u, n_len, (uint32_t)length, o_od};
+    out[0] = u32x4{(noted + 3) & ~3u, n_len, (uint32_t)length, o_od};
     out[1] = u32x4{o_key, o_val, (uint32_t)klen, (uint32_t)vlen};
     out[2] = u32x4{hc, (uint32_t)st, 0, 0};
 }
@@ -692,8 +710,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     // from the shape, which changes only after the flush.
     struct {
         bool any, one_piece;
-        uint32_t m;
-        uint64_t r0, piece;
+        uint32_t m, r0, piece;
         uint32_t start, attributes, slot;
         int32_t ts, od;
     } late;
@@ -717,7 +734,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         }
         if (shape.hc == 0) return;
         if (late.one_piece) {
-            uint32_t o = (late.slot - (uint32_t)late.piece) * 16;
+            uint32_t o = (late.slot - late.piece) * 16;
             for (uint32_t j = 0; j < shape.hc; j++, o += 16) {
                 u32x4 e = htab[j];
                 if (live)
@@ -735,11 +752,13 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     auto fitting = [&](uint32_t at, uint32_t m) -> uint32_t {
         if (shape.n_checks == 0) return 0;
         uint32_t diff = 0;
-        // two compares at a time so that the LDS reads overlap
-        for (uint32_t s = 0; s < shape.n_checks; s += 2) {
-            u32x4 e0 = tab[s], e1 = tab[s + 1];
+        // four compares at a time so that the ring reads overlap (the table is
+        // padded with compares that always hold)
+        for (uint32_t s = 0; s < shape.n_checks; s += 4) {
+            u32x4 e0 = tab[s], e1 = tab[s + 1], e2 = tab[s + 2], e3 = tab[s + 3];
             uint32_t w0 = ring.read32(at + e0.x), w1 = ring.read32(at + e1.x);
-            diff |= ((w0 ^ e0.z) & e0.y) | ((w1 ^ e1.z) & e1.y);
+            uint32_t w2 = ring.read32(at + e2.x), w3 = ring.read32(at + e3.x);
+            diff |= ((w0 ^ e0.z) & e0.y) | ((w1 ^ e1.z) & e1.y) | ((w2 ^ e2.z) & e2.y) | ((w3 ^ e3.z) & e3.y);
         }
         uint64_t fits = __ballot((uint32_t)lane < m && diff == 0);
         return uni(~fits ? (uint32_t)__ffsll((long long)~fits) - 1 : 64);
@@ -857,18 +876,15 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             late.one_piece = true;
             late.piece = 0;
             bool full = false;
-            if (shape.hc) {
-                bool live = (uint32_t)lane < m;
-                full = !runs.take(live ? shape.hc : 0u, m, count - k - m, lane, late.slot, late.piece,
-                                  late.one_piece);
-            }
+            if (shape.hc)
+                full = !runs.take_uniform(shape.hc, m, count - k - m, lane, late.slot, late.piece, late.one_piece);
             if (full) {
                 if (lane == 0) c.status[b] = NISSHI_CAPACITY;
                 k = count;  // ends the walk, the batch has its status
             } else {
                 late.any = true;
                 late.m = m;
-                late.r0 = rbase + k;
+                late.r0 = (uint32_t)rbase + k;
                 late.start = start;
                 pos += m * S;
                 k += m;
