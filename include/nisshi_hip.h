@@ -183,6 +183,13 @@ int nisshi_hip_encode(nisshi_hip_ctx *ctx, const nisshi_columns *cols, uint32_t 
                       const uint64_t *src_data_off, uint8_t *out, uint64_t out_cap,
                       uint64_t *out_off, nisshi_totals *totals);
 
+/* Page-locked host memory for the host-buffer entry points: blobs and columns
+ * in buffers from here move over PCIe by DMA at link speed; any other host
+ * memory works too, staged by the HIP runtime and several times slower.  (The
+ * reference has no counterpart: its batches never leave host memory.) */
+int nisshi_hip_host_alloc(nisshi_hip_ctx *ctx, uint64_t bytes, void **ptr);
+void nisshi_hip_host_free(nisshi_hip_ctx *ctx, void *ptr);
+
 /* CRC-32C of a device buffer (crc-fast "Crc32Iscsi", used at deflated.rs:158-161). */
 int nisshi_hip_crc32c_dev(nisshi_hip_ctx *ctx, const uint8_t *d_data, uint64_t len, uint32_t *crc,
                           void *stream);

@@ -22,6 +22,7 @@ EXPORTS = [
     "nisshi_records_prefix_encode", "nisshi_hip_count_dev", "nisshi_hip_decode_dev",
     "nisshi_hip_encode_dev", "nisshi_hip_decode", "nisshi_hip_encode", "nisshi_hip_crc32c_dev",
     "nisshi_hip_profile_enable", "nisshi_hip_profile_get", "nisshi_hip_profile_name",
+    "nisshi_hip_host_alloc", "nisshi_hip_host_free",
 ]
 
 
@@ -55,6 +56,9 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
     lib.nisshi_hip_ctx_destroy.argtypes = [vp]
     lib.nisshi_hip_ctx_destroy.restype = None
+    lib.nisshi_hip_host_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
+    lib.nisshi_hip_host_free.argtypes = [vp, vp]
+    lib.nisshi_hip_host_free.restype = None
     lib.nisshi_hip_status_str.argtypes = [i32]
     lib.nisshi_hip_status_str.restype = ctypes.c_char_p
     lib.nisshi_hip_last_error.argtypes = [vp]
@@ -166,9 +170,13 @@ class Codec:
         if st:
             raise NisshiError(st, "ctx_create")
         self.ctx = ctx
+        self._pinned = []
 
     def close(self):
         if getattr(self, "ctx", None):
+            for ptr in getattr(self, "_pinned", []):
+                self.lib.nisshi_hip_host_free(self.ctx, ptr)
+            self._pinned = []
             self.lib.nisshi_hip_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -249,6 +257,36 @@ class Codec:
         return out.value
 
     # ---- host-buffer path -----------------------------------------------------
+    def pinned(self, shape, dtype) -> np.ndarray:
+        """A numpy array in page-locked memory from nisshi_hip_host_alloc (freed with
+        the codec): blobs and columns held in such arrays cross PCIe by DMA."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        ptr = ctypes.c_void_p()
+        self._check(self.lib.nisshi_hip_host_alloc(self.ctx, n, ctypes.byref(ptr)))
+        self._pinned.append(ptr)
+        buf = (ctypes.c_uint8 * max(n, 1)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def pinned_columns(self, n_batches: int, rec_cap: int, hdr_cap: int) -> dict:
+        """Host arrays in the device layout, page-locked."""
+        counts = (n_batches, rec_cap, hdr_cap)
+        out = {}
+        for name, dt, words, level in C.DEVICE_ARRAYS:
+            n = max(counts[level], 1)
+            out[name] = self.pinned((n, words) if words > 1 else (n,), dt)
+        return out
+
+    def decode_into(self, blob: np.ndarray, batch_off: np.ndarray, arrays: dict, rec_cap: int,
+                    hdr_cap: int, by_value: bool = True) -> "Totals":
+        """Decode host bytes into caller-held arrays in the device layout (pinned or not)."""
+        cc = C.as_c(arrays)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_decode(
+            self.ctx, blob.ctypes.data if len(blob) else None, len(blob), batch_off.ctypes.data,
+            len(batch_off) - 1, int(by_value), ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(totals)))
+        return totals
+
     def decode(self, blob: bytes, batch_off, by_value: bool = True, rec_cap: Optional[int] = None,
                hdr_cap: Optional[int] = None):
         """Decode host bytes; returns (cols: dict of numpy arrays, totals)."""

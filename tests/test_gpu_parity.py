@@ -354,3 +354,22 @@ def test_full_size_properties(codec, name):
     te = codec.encode_dev(cols, n_b, d_blob, t["data_off"], out, len(blob), out_off)
     assert te.out_bytes == len(blob)
     assert bool((out[:len(blob)] == d_blob[:len(blob)]).all())
+
+
+def test_host_api_with_pinned_buffers(codec):
+    """The host-buffer entry point reading a page-locked blob and writing page-locked
+    columns gives what it gives with ordinary memory: the oracle's columns."""
+    shape, counts, seed = synth.config("c2", 8 / 8192)
+    blob, off, nr, nh = synth.make_batches(shape, counts, seed)
+    crc_patch(codec, blob, off)
+    n_b = len(counts)
+    p_blob = codec.pinned((len(blob),), np.uint8)
+    p_blob[:] = np.frombuffer(bytes(blob), dtype=np.uint8)
+    p_off = np.ascontiguousarray(off, dtype=np.uint64)
+    arrays = codec.pinned_columns(n_b, nr, nh + 4096 * n_b)
+    totals = codec.decode_into(p_blob, p_off, arrays, nr, nh + 4096 * n_b)
+    assert (totals.n_records, totals.n_failed) == (nr, 0)
+    st, c, _, _ = oracle.decode_columns(blob, off)
+    assert st == 0
+    from tansu_amd import columns as C
+    assert_same(C.unpack(arrays), c, n_b)
