@@ -579,21 +579,24 @@ struct Shape {
     uint32_t hc;
 };
 
-// Unaligned reads of the wave's LDS ring.  `at` is a position in the record data
-// plus the distance of the record data from the ring's origin.
+// Reads of the wave's LDS ring at any byte position.  `at` is a position in the
+// record data plus the distance of the record data from the ring's origin.  The
+// LDS is read in aligned dwords and the bytes wanted are shifted out of them:
+// an LDS read that is not aligned stalls the LDS pipeline of the whole CU for
+// tens of cycles, and the walk makes a dozen reads a round in every wave.  (A
+// read may run up to eight bytes past the ring's end, into its guard.)
 struct RingView {
     const lds_u32 *ring;
     __device__ __forceinline__ uint32_t read32(uint32_t at) const {
-        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-        typedef __attribute__((address_space(3))) const u32_unaligned lds_u32u;
-        typedef __attribute__((address_space(3))) const uint8_t lds_u8;
-        return *(lds_u32u *)((lds_u8 *)ring + (at & (kRingBytes - 1)));
+        const lds_u32 *p = ring + ((at & (kRingBytes - 1)) >> 2);
+        return __builtin_amdgcn_alignbyte(p[1], p[0], at & 3);
     }
     __device__ __forceinline__ uint64_t read64(uint32_t at) const {
-        typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-        typedef __attribute__((address_space(3))) const u64_unaligned lds_u64;
-        typedef __attribute__((address_space(3))) const uint8_t lds_u8;
-        return *(lds_u64 *)((lds_u8 *)ring + (at & (kRingBytes - 1)));
+        const lds_u32 *p = ring + ((at & (kRingBytes - 1)) >> 2);
+        uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, at & 3);
+        uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, at & 3);
+        return ((uint64_t)hi << 32) | lo;
     }
 };
 
