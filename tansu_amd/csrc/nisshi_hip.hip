@@ -571,6 +571,7 @@ constexpr uint32_t kShapeWords = (kShapeChecks + kShapeHdrs + 3) * 4;  // and th
 
 struct Shape {
     uint32_t n_checks;  // 0: none learnt
+    uint32_t size;      // bytes of a record of this shape, its length varint included
     uint32_t n_len;     // bytes of the length varint
     int32_t length;     // its value
     uint32_t o_od;      // offsets from the start of the record
@@ -704,6 +705,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     lds_u128 *htab = tab + kShapeChecks;
     Shape shape;
     shape.n_checks = 0;
+    shape.size = 0;
     shape.hc = 0;
     // The stores of a round are issued in the next round, after that round's rows
     // have been taken from the look-ahead queue and before the queue is refilled:
@@ -817,56 +819,65 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         flush();  // the stores of the round before, behind the loads: no wait in between
         lds_order();
         PHASE(3)
-        // ---- where the records start
-        uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
-        bool in = (uint32_t)lane < lanes && guess64 < data_len;
-        uint32_t start = in ? (uint32_t)guess64 : 0;
-        int32_t len = 0;
-        uint32_t used = 0;
-        bool ok = in && fast_varint(ring.read64(start + bias), used, len);
-        // the whole record lies inside the data (this also catches a varint cut short)
-        ok = ok && len >= 0 && (uint64_t)start + used + (uint32_t)len <= data_len;
-        uint32_t size = ok ? used + (uint32_t)len : 0;
-        uint64_t okmask = __ballot(ok);
-        uint64_t same = __ballot(ok && size == S);
-        uint32_t m = uni(~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64);
-        if (!(okmask & 1)) {
-            st = kWalkExact;
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // as at the end of the pass
-            break;
-        }
-        PHASE(4)
+        // ---- which records the round takes: m of them, one a lane from `pos` on
+        uint32_t start = pos + (uint32_t)lane * S;
+        uint32_t at = start + bias;
+        uint32_t m = 0;
+        // The usual round: the records have the size of the shape in hand and lie
+        // inside the data, so testing them against the shape finds them; no
+        // separate look at their lengths is needed (the shape holds the bytes of
+        // the length).
+        if (shape.n_checks && shape.size == S && (uint64_t)pos + (uint64_t)lanes * S <= data_len)
+            m = fitting(at, lanes);
         if (m == 0) {
-            S = uni(size);  // lane 0 is a record, of another size: guess again with that
-            cap = reach(S);
-        } else {
-            // ---- which of them have the shape in hand; learn the first one's if it has not
-            uint32_t at = start + bias;
-            uint32_t fit = fitting(at, m);
-            if (fit == 0) {
-                if (lane == 0) learn_shape(tab, ring, pos + bias, S);
-                lds_order();
-                const lds_u128 *in4 = htab + kShapeHdrs;
-                u32x4 a = in4[0], b4 = in4[1], c4 = in4[2];
-                st = (int)uni(c4.y);
-                shape.n_checks = st == kWalkDone ? uni(a.x) : 0;
-                shape.n_len = uni(a.y);
-                shape.length = (int32_t)uni(a.z);
-                shape.o_od = uni(a.w);
-                shape.o_key = uni(b4.x);
-                shape.o_val = uni(b4.y);
-                shape.klen = (int32_t)uni(b4.z);
-                shape.vlen = (int32_t)uni(b4.w);
-                shape.hc = uni(c4.x);
-                fit = fitting(at, m);
-                if (st == kWalkDone && fit == 0) st = kWalkExact;  // cannot happen: a record fits its own shape
+            // ---- where the records start: lane i decodes the length at pos + i * S
+            uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
+            bool in = (uint32_t)lane < lanes && guess64 < data_len;
+            if (!in) start = 0, at = bias;
+            int32_t len = 0;
+            uint32_t used = 0;
+            bool ok = in && fast_varint(ring.read64(at), used, len);
+            // the whole record lies inside the data (this also catches a varint cut short)
+            ok = ok && len >= 0 && (uint64_t)start + used + (uint32_t)len <= data_len;
+            uint32_t size = ok ? used + (uint32_t)len : 0;
+            uint64_t okmask = __ballot(ok);
+            uint64_t same = __ballot(ok && size == S);
+            uint32_t same_size = uni(~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64);
+            if (!(okmask & 1)) {
+                st = kWalkExact;
+            } else if (same_size == 0) {
+                S = uni(size);  // lane 0 is a record, of another size: guess again with that
+                cap = reach(S);
+            } else {
+                // ---- which of them have the shape in hand; learn the first one's if it has not
+                m = fitting(at, same_size);
+                if (m == 0) {
+                    if (lane == 0) learn_shape(tab, ring, pos + bias, S);
+                    lds_order();
+                    const lds_u128 *in4 = htab + kShapeHdrs;
+                    u32x4 a = in4[0], b4 = in4[1], c4 = in4[2];
+                    st = (int)uni(c4.y);
+                    shape.n_checks = st == kWalkDone ? uni(a.x) : 0;
+                    shape.size = S;
+                    shape.n_len = uni(a.y);
+                    shape.length = (int32_t)uni(a.z);
+                    shape.o_od = uni(a.w);
+                    shape.o_key = uni(b4.x);
+                    shape.o_val = uni(b4.y);
+                    shape.klen = (int32_t)uni(b4.z);
+                    shape.vlen = (int32_t)uni(b4.w);
+                    shape.hc = uni(c4.x);
+                    m = fitting(at, same_size);
+                    if (st == kWalkDone && m == 0) st = kWalkExact;  // cannot happen: a record fits its own shape
+                }
             }
             if (st != kWalkDone) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // as at the end of the pass
                 break;
             }
-            m = fit;
-            PHASE(5)
+        }
+        PHASE(5)
+        if (m) {
             // ---- the free fields of the records that fit
             uint32_t w_used;
             int64_t ts;
