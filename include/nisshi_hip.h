@@ -16,6 +16,12 @@
  *   From<deflated::Batch> for Bytes                 src/record/deflated.rs:84-106
  *   records-blob framing                            src/de.rs:701-720, 1056-1093; src/ser.rs:484-489, 521-574
  *
+ * and, as operators on the decoded columns, two callers of that path in
+ * nisshi-storage:
+ *
+ *   the produce seam of the SQL engines             nisshi-storage/src/pg.rs:797-943, lite.rs:703-815
+ *   combine (the produce queue)                     nisshi-storage/src/batch.rs:661-709
+ *
  * Decoded batches are columns, not Vec<Record>.  Span
  * offsets are relative to the batch's record_data, mirroring the zero-copy
  * Bytes::split_to slices of the reference (src/record/codec.rs:65-76): a null
@@ -46,7 +52,8 @@ enum {
     NISSHI_COMPRESSED = 6,          /* attributes & 7 in 1..4: not decoded here */
     NISSHI_CAPACITY = 7,            /* an output array is too small */
     NISSHI_DEVICE_ERROR = 8,        /* a HIP call failed; see nisshi_hip_last_error */
-    NISSHI_INVALID_ARGUMENT = 9
+    NISSHI_INVALID_ARGUMENT = 9,
+    NISSHI_NONE = 10                /* combine of no batches: Ok(None), nisshi-storage/src/batch.rs:666-668 */
 };
 
 /* Decoded records are columns, grouped so that the fields the decoder produces
@@ -155,7 +162,11 @@ int nisshi_hip_count_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t bl
  * runs between batches is not defined and a batch may leave up to 4096 slots of
  * its last run unused, so size hdr_cap with that slack (a batch whose headers
  * do not fit gets NISSHI_CAPACITY).  Batches whose records all carry the same
- * number of headers use exactly their header count. */
+ * number of headers use exactly their header count.  A batch that ends on the
+ * sequential walk (totals.n_exact: a record whose length disagrees with its
+ * fields, or one that does not decode) starts over with fresh slots and leaves
+ * those of its first attempt unused; headers + 4096 slots more a batch, or
+ * blob_len / 2 + 4096 * n_batches in all, cover that too. */
 int nisshi_hip_decode_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
                           const uint64_t *d_batch_off, uint32_t n_batches, int by_value,
                           const nisshi_columns *d_cols, uint64_t rec_cap, uint64_t hdr_cap,
@@ -182,6 +193,71 @@ int nisshi_hip_encode(nisshi_hip_ctx *ctx, const nisshi_columns *cols, uint32_t 
                       uint64_t n_records, uint64_t n_headers, const uint8_t *src, uint64_t src_len,
                       const uint64_t *src_data_off, uint8_t *out, uint64_t out_cap,
                       uint64_t *out_off, nisshi_totals *totals);
+
+/* ---- the produce seam of the SQL engines (nisshi-storage/src/pg.rs:797-943,
+ * lite.rs:703-815).  The reference inflates the batch into Vec<Record> and walks
+ * it twice to write one row a record (offset, attributes, timestamp, key,
+ * value) and one row a header (offset, key, value).  Here the rows are columns
+ * beside the decoded ones: key, value and header spans stay where the decode
+ * put them (rkey, rval, hdr), the row's attributes are the batch's. */
+typedef struct nisshi_rows {
+    int64_t *offset;     /* per record slot: high + index in the batch (pg.rs:868-869) */
+    int64_t *timestamp;  /* per record slot: base_timestamp + timestamp_delta, ms since the epoch (pg.rs:876) */
+    uint32_t *batch;     /* per record slot: the owning batch; 0xFFFFFFFF for a slot that holds no record */
+    int64_t *hdr_offset; /* per header slot: the offset of the header's record (pg.rs:913-914, 924) */
+    int32_t *status;     /* per batch: the decode status, or NISSHI_TRY_FROM_INT (see check_time) */
+} nisshi_rows;
+
+/* d_cols: columns filled by nisshi_hip_decode_dev with by_value != 0 for n_batches
+ * batches; n_slots: its totals.n_records (or rec_cap); d_high: per batch, the
+ * partition's high watermark, 0 where the reference has None
+ * (high.unwrap_or_default()).  check_time != 0 fails a batch that holds a negative
+ * timestamp with NISSHI_TRY_FROM_INT, as to_system_time does for the PostgreSQL
+ * engine (nisshi-sans-io/src/lib.rs:2189-2193); 0 stores the sum as it is, like
+ * lite.rs:791.  The rows of a batch whose status is not NISSHI_OK are undefined.
+ * Only enqueues work. */
+int nisshi_hip_produce_rows_dev(nisshi_hip_ctx *ctx, const nisshi_columns *d_cols, uint32_t n_batches,
+                                uint64_t n_slots, uint64_t hdr_cap, const int64_t *d_high,
+                                int check_time, const nisshi_rows *d_rows, void *stream);
+
+/* Host-buffer form: decode (by value) and rows in one call, all outputs copied
+ * back.  cols and rows hold host pointers sized rec_cap / hdr_cap. */
+int nisshi_hip_produce_rows(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
+                            const uint64_t *batch_off, uint32_t n_batches, const int64_t *high,
+                            int check_time, const nisshi_columns *cols, const nisshi_rows *rows,
+                            uint64_t rec_cap, uint64_t hdr_cap, nisshi_totals *totals);
+
+/* ---- combine (nisshi-storage/src/batch.rs:661-709): the batches queued for one
+ * topic partition become one batch.  Group g is batches d_group_off[g] ..
+ * d_group_off[g + 1] of d_cols (n_groups + 1 ascending entries, the last at most
+ * n_batches); its first batch is the sink.  In place, for the records of every
+ * later member:
+ *     offset_delta    += sink.last_offset_delta + 1        (running, batch.rs:689, 697)
+ *     timestamp_delta += sink.base_timestamp - base_timestamp            (batch.rs:690-691)
+ * length and all other fields stay, and span offsets are rebased to the sink's
+ * record data, so the members must lie after the sink in the blob, within
+ * 4 GiB (else NISSHI_CAPACITY).  The per-batch arrays of d_out (n_groups entries
+ * each) receive the sink: the first member's header with last_offset_delta and
+ * max_timestamp combined (batch.rs:697-698), record_count, rec_base, data_off;
+ * status = the first member's status that is not NISSHI_OK (the whole combine
+ * fails, as at batch.rs:670, 677; such a group's records are left untouched),
+ * or NISSHI_NONE for an empty group.  d_out's per-record and per-header pointers
+ * are not used: to deflate the sinks (batch.rs:706) pass d_out with d_cols'
+ * record and header pointers to nisshi_hip_encode_dev, and d_out->data_off as
+ * d_src_data_off.  Sums wrap, as in a release build of the reference.  d_cols
+ * must come from a decode with by_value != 0.  Only enqueues work. */
+int nisshi_hip_combine_dev(nisshi_hip_ctx *ctx, const nisshi_columns *d_cols, uint32_t n_batches,
+                           uint64_t n_slots, uint64_t hdr_cap, const uint32_t *d_group_off,
+                           uint32_t n_groups, const nisshi_columns *d_out, void *stream);
+
+/* Host-buffer form: inflate, combine and deflate in one call.  blob holds
+ * n_batches deflated batches; out receives one deflated batch a group
+ * (out_off: n_groups + 1 offsets; a group that fails or is empty has no bytes),
+ * group_status one status a group. */
+int nisshi_hip_combine(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
+                       const uint64_t *batch_off, uint32_t n_batches, const uint32_t *group_off,
+                       uint32_t n_groups, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
+                       int32_t *group_status, nisshi_totals *totals);
 
 /* Page-locked host memory for the host-buffer entry points: blobs and columns
  * in buffers from here move over PCIe by DMA at link speed; any other host

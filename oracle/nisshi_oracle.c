@@ -694,3 +694,109 @@ int no_builder_columns(const no_columns *c, size_t n_batches, const uint8_t *src
     }
     return NO_OK;
 }
+
+/* ------------------------------------------------------------------ callers */
+
+/* by-value inflate: deflated parse, BatchAttribute round trip with the
+ * compression cleared (inflated.rs:123-140), the records (deflated.rs:421-459) */
+static int inflate_by_value(const uint8_t *buf, size_t len, no_deflated_batch *d, no_record **recs,
+                            size_t *n) {
+    int st = no_deflated_parse(buf, len, d);
+    if (st) return st;
+    int16_t cleared;
+    st = no_attributes_clear_compression(d->attributes, &cleared);
+    if (st) return st;
+    st = no_inflate_records(d, recs, n);
+    if (st) return st;
+    d->attributes = cleared; /* only an uncompressed batch gets here */
+    return NO_OK;
+}
+
+/* pg.rs:797-943 (check_time) and lite.rs:703-815 (!check_time) */
+int no_produce_rows(const uint8_t *batch, size_t len, int64_t high, int check_time,
+                    size_t row_cap, size_t hdr_cap, int16_t *attributes,
+                    int64_t *row_offset, int64_t *row_timestamp,
+                    uint64_t *row_key_pos, int64_t *row_key_len,
+                    uint64_t *row_val_pos, int64_t *row_val_len,
+                    int64_t *hdr_offset, uint64_t *hdr_key_pos, int64_t *hdr_key_len,
+                    uint64_t *hdr_val_pos, int64_t *hdr_val_len,
+                    size_t *n_rows, size_t *n_hdrs) {
+    no_deflated_batch d;
+    no_record *recs = NULL;
+    size_t n = 0, nh = 0;
+    *n_rows = *n_hdrs = 0;
+    int st = inflate_by_value(batch, len, &d, &recs, &n); /* pg.rs:797 */
+    if (st) return st;
+    *attributes = d.attributes;
+    for (size_t i = 0; i < n && st == NO_OK; i++) { /* pg.rs:867-897 */
+        const no_record *r = &recs[i];
+        if (i >= row_cap) { st = NO_CAPACITY; break; }
+        row_offset[i] = (int64_t)((uint64_t)high + (uint64_t)i);
+        int64_t ts = (int64_t)((uint64_t)d.base_timestamp + (uint64_t)r->timestamp_delta);
+        if (check_time && ts < 0) { st = NO_TRY_FROM_INT; break; } /* lib.rs:2189-2193 */
+        row_timestamp[i] = ts;
+        row_key_pos[i] = (uint64_t)(r->key.ptr - batch);
+        row_key_len[i] = r->key.len;
+        row_val_pos[i] = (uint64_t)(r->value.ptr - batch);
+        row_val_len[i] = r->value.len;
+    }
+    for (size_t i = 0; i < n && st == NO_OK; i++) { /* pg.rs:912-936 */
+        const no_record *r = &recs[i];
+        for (size_t j = 0; j < r->n_headers; j++) {
+            if (nh >= hdr_cap) { st = NO_CAPACITY; break; }
+            hdr_offset[nh] = (int64_t)((uint64_t)high + (uint64_t)i);
+            hdr_key_pos[nh] = (uint64_t)(r->headers[j].key.ptr - batch);
+            hdr_key_len[nh] = r->headers[j].key.len;
+            hdr_val_pos[nh] = (uint64_t)(r->headers[j].value.ptr - batch);
+            hdr_val_len[nh] = r->headers[j].value.len;
+            nh++;
+        }
+    }
+    no_records_free(recs, n);
+    if (st) return st;
+    *n_rows = n;
+    *n_hdrs = nh;
+    return NO_OK;
+}
+
+/* batch.rs:661-709 */
+int no_combine(const uint8_t *const *batches, const size_t *lens, size_t n, uint8_t *out,
+               size_t out_cap, size_t *out_len, int *is_none) {
+    *out_len = 0;
+    *is_none = 0;
+    if (n == 0) { /* :666-668 */
+        *is_none = 1;
+        return NO_OK;
+    }
+    no_deflated_batch sink;
+    no_record *all = NULL;
+    size_t total = 0;
+    int st = inflate_by_value(batches[0], lens[0], &sink, &all, &total); /* :670 */
+    if (st) return st;
+    for (size_t b = 1; b < n; b++) { /* :676-699 */
+        no_deflated_batch d;
+        no_record *recs = NULL;
+        size_t m = 0;
+        st = inflate_by_value(batches[b], lens[b], &d, &recs, &m); /* :677 */
+        if (st) {
+            no_records_free(all, total);
+            return st;
+        }
+        all = (no_record *)realloc(all, (total + m + 1) * sizeof(no_record));
+        for (size_t i = 0; i < m; i++) { /* :684-695; the moved record keeps its header vector */
+            no_record r = recs[i];
+            r.offset_delta = (int32_t)((uint32_t)r.offset_delta + (uint32_t)sink.last_offset_delta + 1u);
+            r.timestamp_delta = (int64_t)((uint64_t)r.timestamp_delta +
+                                          ((uint64_t)sink.base_timestamp - (uint64_t)d.base_timestamp));
+            all[total + i] = r;
+        }
+        total += m;
+        free(recs); /* the records themselves moved into `all` */
+        sink.last_offset_delta =
+            (int32_t)((uint32_t)sink.last_offset_delta + (uint32_t)d.last_offset_delta + 1u); /* :697 */
+        if (d.max_timestamp > sink.max_timestamp) sink.max_timestamp = d.max_timestamp;      /* :698 */
+    }
+    st = no_deflate(&sink, all, total, out, out_cap, out_len); /* :706 */
+    no_records_free(all, total);
+    return st;
+}

@@ -214,6 +214,43 @@ int no_encode_columns(const no_columns *cols, size_t n_batches, const uint8_t *s
 int no_builder_columns(const no_columns *cols, size_t n_batches, const uint8_t *src,
                        const uint64_t *src_data_off, int32_t *batch_length, uint32_t *crc);
 
+/* ---- callers of the codec in nisshi-storage, restated at the record level so
+ * that the column operators of the HIP library can be checked against them ---- */
+
+/* The produce seam of the SQL engines: inflated::Batch::try_from(deflated), then
+ * one row per record and one per header (nisshi-storage/src/pg.rs:797-943).
+ *   row offset     high.unwrap_or_default() + index                pg.rs:867-869, 912-914
+ *   row timestamp  base_timestamp + timestamp_delta (milliseconds) pg.rs:876
+ *   row attributes the batch's, after the by-value normalisation   pg.rs:870
+ * check_time != 0 follows pg.rs:876, where to_system_time (nisshi-sans-io/src/lib.rs:
+ * 2189-2193) turns a negative timestamp into Error::TryFromInt; 0 follows
+ * nisshi-storage/src/lite.rs:762-815, which stores the sum as it is.
+ * Spans are positions in `batch`.  hdr_* rows are in record order, each with
+ * the offset of its record. */
+int no_produce_rows(const uint8_t *batch, size_t len, int64_t high, int check_time,
+                    size_t row_cap, size_t hdr_cap, int16_t *attributes,
+                    int64_t *row_offset, int64_t *row_timestamp,
+                    uint64_t *row_key_pos, int64_t *row_key_len,
+                    uint64_t *row_val_pos, int64_t *row_val_len,
+                    int64_t *hdr_offset, uint64_t *hdr_key_pos, int64_t *hdr_key_len,
+                    uint64_t *hdr_val_pos, int64_t *hdr_val_len,
+                    size_t *n_rows, size_t *n_hdrs);
+
+/* combine, nisshi-storage/src/batch.rs:661-709: the batches queued for one
+ * topic partition become one.  The first batch is the sink; the records of each
+ * later batch are appended with
+ *   offset_delta    += sink.last_offset_delta + 1
+ *   timestamp_delta += sink.base_timestamp - batch.base_timestamp
+ * (length and everything else as they were), then
+ *   sink.last_offset_delta += batch.last_offset_delta + 1
+ *   sink.max_timestamp      = max(sink.max_timestamp, batch.max_timestamp)
+ * and the sink is deflated again (deflated.rs:392-409).  Integer sums wrap, as
+ * they do in a release build of the reference.  n == 0 gives *is_none = 1
+ * (Ok(None), batch.rs:666-668).  The first batch that fails to inflate gives
+ * its status. */
+int no_combine(const uint8_t *const *batches, const size_t *lens, size_t n, uint8_t *out,
+               size_t out_cap, size_t *out_len, int *is_none);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1132,4 +1132,5 @@ __global__ void crc_buffer_finish_kernel(const uint8_t *data, uint64_t len, uint
 }  // namespace nisshi
 
 #include "encode.inc"
+#include "storage.inc"
 #include "api.inc"

@@ -23,6 +23,8 @@ EXPORTS = [
     "nisshi_hip_encode_dev", "nisshi_hip_decode", "nisshi_hip_encode", "nisshi_hip_crc32c_dev",
     "nisshi_hip_profile_enable", "nisshi_hip_profile_get", "nisshi_hip_profile_name",
     "nisshi_hip_host_alloc", "nisshi_hip_host_free",
+    "nisshi_hip_produce_rows_dev", "nisshi_hip_produce_rows", "nisshi_hip_combine_dev",
+    "nisshi_hip_combine",
 ]
 
 
@@ -32,11 +34,23 @@ class Totals(ctypes.Structure):
                 ("out_bytes", ctypes.c_uint64)]
 
 
+# `nisshi_rows`: (name, dtype, level) with level 0 per batch, 1 per record slot, 2 per header slot
+ROW_ARRAYS = [("offset", np.int64, 1), ("timestamp", np.int64, 1), ("batch", np.uint32, 1),
+              ("hdr_offset", np.int64, 2), ("status", np.int32, 0)]
+NO_BATCH = 0xFFFFFFFF
+NONE = 10  # NISSHI_NONE
+
+
+class CRows(ctypes.Structure):
+    """ctypes view of `nisshi_rows`."""
+    _fields_ = [(name, ctypes.c_void_p) for name, _, _ in ROW_ARRAYS]
+
+
 class NisshiError(RuntimeError):
     def __init__(self, status, detail=""):
         self.status = status
         name = C.STATUS_NAMES[status] if 0 <= status < len(C.STATUS_NAMES) else \
-            {8: "DEVICE_ERROR", 9: "INVALID_ARGUMENT"}.get(status, str(status))
+            {8: "DEVICE_ERROR", 9: "INVALID_ARGUMENT", 10: "NONE"}.get(status, str(status))
         super().__init__(f"nisshi_hip: {name} {detail}".strip())
 
 
@@ -78,6 +92,14 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_encode.argtypes = [vp, ctypes.POINTER(C.CColumns), u32, u64, u64, vp, u64, vp,
                                       vp, u64, vp, ctypes.POINTER(Totals)]
     lib.nisshi_hip_crc32c_dev.argtypes = [vp, vp, u64, ctypes.POINTER(u32), vp]
+    lib.nisshi_hip_produce_rows_dev.argtypes = [vp, ctypes.POINTER(C.CColumns), u32, u64, u64, vp, i32,
+                                                ctypes.POINTER(CRows), vp]
+    lib.nisshi_hip_produce_rows.argtypes = [vp, vp, u64, vp, u32, vp, i32, ctypes.POINTER(C.CColumns),
+                                            ctypes.POINTER(CRows), u64, u64, ctypes.POINTER(Totals)]
+    lib.nisshi_hip_combine_dev.argtypes = [vp, ctypes.POINTER(C.CColumns), u32, u64, u64, vp, u32,
+                                           ctypes.POINTER(C.CColumns), vp]
+    lib.nisshi_hip_combine.argtypes = [vp, vp, u64, vp, u32, vp, u32, vp, u64, vp, vp,
+                                       ctypes.POINTER(Totals)]
     lib.nisshi_hip_profile_enable.argtypes = [vp, i32]
     lib.nisshi_hip_profile_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     lib.nisshi_hip_profile_name.argtypes = [i32]
@@ -154,6 +176,22 @@ class DeviceColumns:
         for name, dt, words, level in C.DEVICE_ARRAYS:
             arrays[name] = self.t[name][:counts[level]].cpu().numpy().view(dt).copy()
         return C.unpack(arrays)
+
+
+class DeviceRows:
+    """`nisshi_rows` in device memory: one torch tensor per array (`t`)."""
+
+    def __init__(self, n_batches: int, rec_cap: int, hdr_cap: int, device):
+        import torch
+        counts = (n_batches, rec_cap, hdr_cap)
+        self.t = {}
+        self.c = CRows()
+        for name, dt, level in ROW_ARRAYS:
+            self.t[name] = torch.empty(max(counts[level], 1), dtype=_torch_dtype(dt), device=device)
+            setattr(self.c, name, self.t[name].data_ptr())
+
+    def to_host(self) -> dict:
+        return {name: self.t[name].cpu().numpy().view(dt) for name, dt, _ in ROW_ARRAYS}
 
 
 class Codec:
@@ -250,6 +288,29 @@ class Codec:
             ctypes.byref(totals) if sync else None, self._stream()))
         return totals if sync else None
 
+    def produce_rows_dev(self, cols: DeviceColumns, n_batches: int, n_slots: int, d_high,
+                         check_time: bool = True) -> DeviceRows:
+        """Rows of the SQL engines' produce seam from decoded columns (enqueues only)."""
+        rows = DeviceRows(n_batches, n_slots, cols.hdr_cap, self.device)
+        self._check(self.lib.nisshi_hip_produce_rows_dev(
+            self.ctx, ctypes.byref(cols.c), n_batches, n_slots, cols.hdr_cap, d_high.data_ptr(),
+            int(check_time), ctypes.byref(rows.c), self._stream()))
+        return rows
+
+    def combine_dev(self, cols: DeviceColumns, n_batches: int, n_slots: int, d_group_off,
+                    n_groups: int) -> DeviceColumns:
+        """Combine groups of decoded batches in place; returns the sinks' columns, which
+        share the record and header arrays of `cols` (enqueues only)."""
+        sink = DeviceColumns(n_groups, 0, 0, self.device)
+        for name in ("rkey", "rval", "timestamp_delta", "rattributes", "hdr"):
+            sink.t[name] = cols.t[name]
+            setattr(sink.c, name, cols.t[name].data_ptr())
+        sink.rec_cap, sink.hdr_cap = cols.rec_cap, cols.hdr_cap
+        self._check(self.lib.nisshi_hip_combine_dev(
+            self.ctx, ctypes.byref(cols.c), n_batches, n_slots, cols.hdr_cap, d_group_off.data_ptr(),
+            n_groups, ctypes.byref(sink.c), self._stream()))
+        return sink
+
     def crc32c_dev(self, d_data, length: int, offset: int = 0) -> int:
         out = ctypes.c_uint32(0)
         self._check(self.lib.nisshi_hip_crc32c_dev(self.ctx, d_data.data_ptr() + offset, length,
@@ -323,3 +384,50 @@ class Codec:
             soff.ctypes.data if len(soff) else None, out.ctypes.data, out_cap,
             out_off.ctypes.data, ctypes.byref(totals)))
         return out[:totals.out_bytes].tobytes(), out_off, totals
+
+    def produce_rows(self, blob: bytes, batch_off, high, check_time: bool = True,
+                     rec_cap: Optional[int] = None, hdr_cap: Optional[int] = None):
+        """Decode host bytes and form the produce rows; returns (cols, rows, totals)."""
+        arr = np.frombuffer(bytes(blob), dtype=np.uint8)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+        hi = np.ascontiguousarray(high, dtype=np.int64)
+        n_b = len(off) - 1
+        rec_cap = len(arr) // 7 + 1 if rec_cap is None else rec_cap
+        hdr_cap = len(arr) // 2 + 4096 * n_b + 1 if hdr_cap is None else hdr_cap
+        arrays = C.alloc_device_layout(n_b, rec_cap, hdr_cap)
+        cc = C.as_c(arrays)
+        counts = (n_b, rec_cap, hdr_cap)
+        rows = {name: np.zeros(max(counts[level], 1), dtype=dt) for name, dt, level in ROW_ARRAYS}
+        cr = CRows()
+        for name, _, _ in ROW_ARRAYS:
+            setattr(cr, name, rows[name].ctypes.data)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_produce_rows(
+            self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data, n_b,
+            hi.ctypes.data if len(hi) else None, int(check_time), ctypes.byref(cc), ctypes.byref(cr),
+            rec_cap, hdr_cap, ctypes.byref(totals)))
+        nr, nh = min(totals.n_records, rec_cap), min(totals.n_headers, hdr_cap)
+        cols = C.trim(C.unpack(arrays), n_b, nr, nh)
+        used = (n_b, nr, nh)
+        return cols, {name: rows[name][:used[level]] for name, _, level in ROW_ARRAYS}, totals
+
+    def combine(self, blob: bytes, batch_off, group_off, out_cap: Optional[int] = None):
+        """Inflate, combine and deflate groups of batches held in host bytes.  Returns
+        (list of bytes or None per group, group_status np.int32[n_groups], totals)."""
+        arr = np.frombuffer(bytes(blob), dtype=np.uint8)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+        groups = np.ascontiguousarray(group_off, dtype=np.uint32)
+        n_b, n_g = len(off) - 1, len(groups) - 1
+        # rebased deltas may need longer varints: at most 13 bytes more on a record of 7
+        out_cap = 3 * len(arr) + 64 if out_cap is None else out_cap
+        out = np.zeros(max(out_cap, 1), dtype=np.uint8)
+        out_off = np.zeros(n_g + 1, dtype=np.uint64)
+        status = np.zeros(max(n_g, 1), dtype=np.int32)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_combine(
+            self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data, n_b,
+            groups.ctypes.data, n_g, out.ctypes.data, out_cap, out_off.ctypes.data,
+            status.ctypes.data, ctypes.byref(totals)))
+        pieces = [out[int(out_off[g]):int(out_off[g + 1])].tobytes() if status[g] == C.OK else None
+                  for g in range(n_g)]
+        return pieces, status[:n_g], totals

@@ -74,6 +74,10 @@ def _load():
                                       ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_void_p]
     lib.no_builder_columns.argtypes = [ctypes.POINTER(FieldColumns), sz, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.no_produce_rows.argtypes = [vp, sz, i64, ctypes.c_int, sz, sz, vp] + [vp] * 11 + \
+        [ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.no_combine.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int)]
     return lib
 
 
@@ -165,3 +169,44 @@ def builder_columns(cols, n_batches, src, src_data_off):
     st = LIB.no_builder_columns(ctypes.byref(cc), n_batches, src.ctypes.data,
                                 src_data_off.ctypes.data, bl.ctypes.data, crc.ctypes.data)
     return st, bl[:n_batches], crc[:n_batches]
+
+
+ROW_FIELDS = [("offset", np.int64), ("timestamp", np.int64), ("key_pos", np.uint64),
+              ("key_len", np.int64), ("val_pos", np.uint64), ("val_len", np.int64)]
+HDR_ROW_FIELDS = [("offset", np.int64), ("key_pos", np.uint64), ("key_len", np.int64),
+                  ("val_pos", np.uint64), ("val_len", np.int64)]
+
+
+def produce_rows(batch: bytes, high: int, check_time: bool = True):
+    """The rows pg.rs:797-943 writes for one deflated batch.  Returns (status,
+    attributes, rows: dict, header rows: dict); spans are positions in `batch`."""
+    buf = np.frombuffer(bytes(batch), dtype=np.uint8)
+    cap_r, cap_h = len(buf) // 7 + 1, len(buf) // 2 + 1
+    rows = {n: np.zeros(cap_r, dtype=dt) for n, dt in ROW_FIELDS}
+    hrows = {n: np.zeros(cap_h, dtype=dt) for n, dt in HDR_ROW_FIELDS}
+    attributes = np.zeros(1, dtype=np.int16)
+    nr, nh = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    st = LIB.no_produce_rows(buf.ctypes.data if len(buf) else None, len(buf), high, int(check_time),
+                             cap_r, cap_h, attributes.ctypes.data,
+                             *[rows[n].ctypes.data for n, _ in ROW_FIELDS],
+                             *[hrows[n].ctypes.data for n, _ in HDR_ROW_FIELDS],
+                             ctypes.byref(nr), ctypes.byref(nh))
+    return (st, int(attributes[0]), {n: v[:nr.value] for n, v in rows.items()},
+            {n: v[:nh.value] for n, v in hrows.items()})
+
+
+def combine(batches):
+    """combine (batch.rs:661-709) of a list of deflated batches.  Returns (status,
+    bytes or None)."""
+    bufs = [np.frombuffer(bytes(b), dtype=np.uint8) if len(b) else np.zeros(0, dtype=np.uint8)
+            for b in batches]
+    n = len(bufs)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    lens = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in bufs])
+    cap = 3 * sum(len(b) for b in bufs) + 64     # rebased deltas may need longer varints
+    out = np.zeros(cap, dtype=np.uint8)
+    out_len, none = ctypes.c_size_t(0), ctypes.c_int(0)
+    st = LIB.no_combine(ptrs, lens, n, out.ctypes.data, cap, ctypes.byref(out_len), ctypes.byref(none))
+    if st or none.value:
+        return st, None
+    return st, out[:out_len.value].tobytes()

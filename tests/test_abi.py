@@ -60,9 +60,20 @@ def test_columns_struct_matches_header():
             assert fname.endswith(cname.replace("hdr_", "rhdr_")) or fname == cname or fname.endswith(cname), (cname, fname)
 
 
+def test_rows_struct_matches_header():
+    text = open(os.path.join(ROOT, "include", "nisshi_hip.h")).read()
+    body = text[text.index("typedef struct nisshi_rows {"):text.index("} nisshi_rows;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    got = re.findall(r"(u?int\d+_t) \*(\w+);", body)
+    want = [(np.dtype(dt).name + "_t", name)
+            for name, dt, _ in hip.ROW_ARRAYS]
+    assert got == want
+
+
 def test_status_strings(lib):
-    for st in range(10):
-        assert lib.nisshi_hip_status_str(st)
+    for st in range(11):
+        assert lib.nisshi_hip_status_str(st) not in (None, b"unknown status")
+    assert lib.nisshi_hip_status_str(11) == b"unknown status"
     assert b"TryGet" in lib.nisshi_hip_status_str(C.TRY_GET)
 
 

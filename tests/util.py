@@ -86,3 +86,27 @@ def assert_same(gpu: dict, cpu: dict, n_batches: int):
         assert (gpu[name][gh] == cpu[name][ch]).all(), name
 
 
+def body_size(rec: C.Record) -> int:
+    """record::Builder::size_in_bytes (record.rs:363-372): what Record::try_from(Builder)
+    stores in `length`."""
+    def octets(b):
+        return oracle.varint_size(-1 if b is None else len(b)) + (0 if b is None else len(b))
+    n = 1 + oracle.varint_size(rec.timestamp_delta, "i64") + oracle.varint_size(rec.offset_delta)
+    n += octets(rec.key) + octets(rec.value) + oracle.varint_size(len(rec.headers), "u32")
+    for h in rec.headers:
+        n += octets(h.key) + octets(h.value)
+    return n
+
+
+def build_batch(header: dict, records) -> bytes:
+    """A deflated batch as inflated::Batch::builder()...build() then try_into() gives
+    it: every record's length is its body size, record_count, batch_length and crc
+    follow from the records (deflated.rs:392-409)."""
+    recs = [C.Record(body_size(r), r.attributes, r.timestamp_delta, r.offset_delta, r.key, r.value,
+                     r.headers) for r in records]
+    hdr = dict(magic=2, partition_leader_epoch=-1, producer_id=-1)
+    hdr.update(header)
+    cols, payload, src_off = C.columns_from_records([(hdr, recs)])
+    st, out, _ = oracle.encode_columns(cols, 1, payload, src_off)
+    assert st == C.OK
+    return out
