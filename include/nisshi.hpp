@@ -7,6 +7,8 @@
 //   record::deflated::{Batch, Frame}     src/record/deflated.rs:28-106
 //   record::inflated::{Batch, Frame}     src/record/inflated.rs:29-82
 //   Error                                src/lib.rs:328-366
+//   storage::combine                     nisshi-storage/src/batch.rs:661-709
+//   storage::produce_rows                nisshi-storage/src/pg.rs:797-943, lite.rs:703-815
 //
 // Conversions the reference writes as TryFrom/From are static `try_from` /
 // `from` functions here.  The ones that decode or encode records take the Codec
@@ -326,7 +328,8 @@ inline Result<inflated::Frame> inflate(Codec &codec, const deflated::Frame &fram
     }
     // a record is at least seven bytes, a header at least two
     if (rec_cap > blob.size() / 7 + 1) rec_cap = blob.size() / 7 + 1;
-    uint64_t hdr_cap = blob.size() / 2 + 4096 * nb + 1;
+    // (a batch that ends on the sequential walk takes its header slots twice)
+    uint64_t hdr_cap = blob.size() + 4096 * nb + 1;
     HostColumns cols(nb, rec_cap, hdr_cap);
     nisshi_columns c = cols.c();
     nisshi_totals totals{};
@@ -534,4 +537,98 @@ inline Result<deflated::Batch> deflated::Batch::try_from(Codec &codec, const inf
 }
 
 }  // namespace record
+
+// ---------------------------------------------------------------- callers in nisshi-storage
+
+namespace storage {
+
+// combine, batch.rs:661-709: the batches queued for one topic partition become
+// one; the first is the sink, the records of the others are appended with their
+// offset and timestamp deltas moved to the sink's terms, and the sink is
+// deflated again.  No batches give Ok(None) (batch.rs:666-668); the first batch
+// that does not inflate gives its error.  One device call.
+inline Result<std::optional<record::deflated::Batch>> combine(Codec &codec,
+                                                              const std::vector<record::deflated::Batch> &batches) {
+    using record::deflated::Batch;
+    if (batches.empty()) return std::optional<Batch>();
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> off(batches.size() + 1, 0);
+    for (size_t b = 0; b < batches.size(); b++) {
+        Bytes e = batches[b].into_bytes();
+        blob.insert(blob.end(), e.data(), e.data() + e.len());
+        off[b + 1] = blob.size();
+    }
+    const uint32_t group_off[2] = {0, uint32_t(batches.size())};
+    // moved deltas may need longer varints: at most 13 bytes more on a record of 7
+    std::vector<uint8_t> out(3 * blob.size() + 64);
+    uint64_t out_off[2] = {0, 0};
+    int32_t status = 0;
+    nisshi_totals totals{};
+    int st = nisshi_hip_combine(codec.ctx(), blob.data(), blob.size(), off.data(), uint32_t(batches.size()),
+                                group_off, 1, out.data(), out.size(), out_off, &status, &totals);
+    if (st) return Error::from_status(st);
+    if (status) return Error::from_status(status);
+    auto d = Batch::try_from(Bytes(out.data() + out_off[0], size_t(out_off[1] - out_off[0])));
+    if (d.is_err()) return d.error();
+    return std::optional<Batch>(std::move(*d));
+}
+
+// The rows the SQL engines write for a produced batch: record_copy.sql's columns
+// (pg.rs:853-862, without the topic partition id the caller holds) and
+// header_copy.sql's (pg.rs:908).
+struct RecordRow {
+    int64_t offset;      // high.unwrap_or_default() + index, pg.rs:868-869
+    int16_t attributes;  // the batch's, pg.rs:870
+    int64_t timestamp;   // base_timestamp + timestamp_delta, milliseconds since the epoch, pg.rs:876
+    std::optional<Bytes> key, value;
+};
+struct HeaderRow {
+    int64_t offset;  // of the header's record, pg.rs:913-914
+    std::optional<Bytes> key, value;
+};
+struct Rows {
+    std::vector<RecordRow> records;
+    std::vector<HeaderRow> headers;
+};
+
+// pg.rs:797-943: Batch::try_from(deflated) and the two row loops, as one device
+// call.  check_time follows the PostgreSQL engine, where a negative timestamp is
+// Error::TryFromInt (to_system_time, nisshi-sans-io/src/lib.rs:2189-2193); false
+// follows lite.rs:791, which stores the sum as it is.
+inline Result<Rows> produce_rows(Codec &codec, const record::deflated::Batch &deflated,
+                                 std::optional<int64_t> high, bool check_time = true) {
+    Bytes e = deflated.into_bytes();
+    const uint64_t off[2] = {0, e.len()};
+    uint64_t rec_cap = deflated.record_count;
+    if (rec_cap > e.len() / 7 + 1) rec_cap = e.len() / 7 + 1;
+    uint64_t hdr_cap = e.len() + 4096 + 1;
+    record::detail::HostColumns cols(1, rec_cap, hdr_cap);
+    std::vector<int64_t> row_offset(rec_cap + 1), row_ts(rec_cap + 1), hdr_offset(hdr_cap + 1);
+    std::vector<uint32_t> row_batch(rec_cap + 1);
+    int32_t status = 0;
+    nisshi_rows rows{row_offset.data(), row_ts.data(), row_batch.data(), hdr_offset.data(), &status};
+    nisshi_columns c = cols.c();
+    nisshi_totals totals{};
+    const int64_t h = high.value_or(0);
+    int st = nisshi_hip_produce_rows(codec.ctx(), e.data(), e.len(), off, 1, &h, check_time ? 1 : 0, &c, &rows,
+                                     rec_cap, hdr_cap, &totals);
+    if (st) return Error::from_status(st);
+    if (status) return Error::from_status(status, deflated.attributes & 7);
+    Rows out;
+    out.records.reserve(cols.record_count[0]);
+    const Bytes &data = deflated.record_data;
+    for (uint32_t r = cols.rec_base[0]; r < cols.rec_base[0] + cols.record_count[0]; r++) {
+        out.records.push_back(RecordRow{row_offset[r], cols.attributes[0], row_ts[r],
+                                        record::detail::span(data, cols.rkey[r].key_off, cols.rkey[r].key_len),
+                                        record::detail::span(data, cols.rval[r].val_off, cols.rval[r].val_len)});
+    }
+    for (uint32_t r = cols.rec_base[0]; r < cols.rec_base[0] + cols.record_count[0]; r++)
+        for (uint32_t s = cols.rval[r].hdr_base; s < cols.rval[r].hdr_base + uint32_t(cols.rval[r].hdr_count); s++)
+            out.headers.push_back(HeaderRow{hdr_offset[s],
+                                            record::detail::span(data, cols.hdr[s].key_off, cols.hdr[s].key_len),
+                                            record::detail::span(data, cols.hdr[s].val_off, cols.hdr[s].val_len)});
+    return out;
+}
+
+}  // namespace storage
 }  // namespace nisshi

@@ -355,7 +355,8 @@ class Codec:
         off = np.ascontiguousarray(batch_off, dtype=np.uint64)
         n_b = len(off) - 1
         rec_cap = len(arr) // 7 + 1 if rec_cap is None else rec_cap
-        hdr_cap = len(arr) // 2 + 1 if hdr_cap is None else hdr_cap
+        # header slots: see nisshi_hip_decode_dev in include/nisshi_hip.h
+        hdr_cap = len(arr) + 4096 * n_b + 1 if hdr_cap is None else hdr_cap
         arrays = C.alloc_device_layout(n_b, rec_cap, hdr_cap)
         cc = C.as_c(arrays)
         totals = Totals()
@@ -393,7 +394,7 @@ class Codec:
         hi = np.ascontiguousarray(high, dtype=np.int64)
         n_b = len(off) - 1
         rec_cap = len(arr) // 7 + 1 if rec_cap is None else rec_cap
-        hdr_cap = len(arr) // 2 + 4096 * n_b + 1 if hdr_cap is None else hdr_cap
+        hdr_cap = len(arr) + 4096 * n_b + 1 if hdr_cap is None else hdr_cap
         arrays = C.alloc_device_layout(n_b, rec_cap, hdr_cap)
         cc = C.as_c(arrays)
         counts = (n_b, rec_cap, hdr_cap)

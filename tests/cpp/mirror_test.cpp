@@ -1,6 +1,6 @@
 // Tests of include/nisshi.hpp written after the reference's own unit tests
 // (nisshi-sans-io/src/record/inflated.rs:533-618, src/record.rs:478-523,
-// src/record/deflated.rs tests): the same golden bytes and the same expectations,
+// src/record/deflated.rs tests, nisshi-storage/src/batch.rs:1198-1349): the same golden bytes and the same expectations,
 // through the C++ types that mirror the reference's.  `mirror_test cpu` runs the
 // cases that need no device, `mirror_test gpu` all of them.
 #include <cstdio>
@@ -159,6 +159,117 @@ static void truncated_record_data_is_an_error(Codec &codec) {
     CHECK(r.is_err() && r.error().kind == Error::TryGet);
 }
 
+// batch.rs:1204-1242: one batch per list of values
+static std::vector<deflated::Batch> into_batches(Codec &codec, int16_t attributes, int64_t producer_id,
+                                                 int16_t producer_epoch, int64_t base_offset,
+                                                 const std::vector<std::vector<std::string>> &batches) {
+    std::vector<deflated::Batch> split;
+    int32_t base_sequence = 0;
+    int64_t ts = 1700000000000;
+    for (const auto &batch : batches) {
+        inflated::Batch ib;
+        ib.attributes = attributes;
+        ib.producer_id = producer_id;
+        ib.producer_epoch = producer_epoch;
+        ib.base_offset = base_offset;
+        ib.last_offset_delta = int32_t(batch.size()) - 1;
+        ib.base_sequence = base_sequence;
+        ib.base_timestamp = ib.max_timestamp = ts;
+        ts += 250;  // Builder::default takes the time of day: later batches are later
+        int32_t offset_delta = 0;
+        for (const auto &value : batch) {
+            Record r;
+            r.value = bytes_of(value.c_str());
+            r.offset_delta = offset_delta++;
+            r.length = int32_t(6 + value.size());  // the body: five one-byte fields, the value, no headers
+            ib.records.push_back(r);
+        }
+        split.push_back(deflated::Batch::try_from(codec, ib).unwrap());
+        base_sequence += int32_t(batch.size());
+    }
+    return split;
+}
+
+// batch.rs:1198-1202
+static void combine_empty(Codec &codec) {
+    auto r = storage::combine(codec, {});
+    CHECK(r.is_ok() && !r->has_value());
+}
+
+// batch.rs:1244-1349
+static void combine_batches(Codec &codec) {
+    const std::vector<std::vector<std::string>> batches = {{"a", "b", "c"}, {"f", "g"}, {"i"}, {"j"}, {"k"},
+                                                            {"p", "q", "r", "s"}};
+    const int64_t producer_id = 54345, base_offset = 0;
+    const int16_t producer_epoch = 32123, attributes = 0;
+    auto split = into_batches(codec, attributes, producer_id, producer_epoch, base_offset, batches);
+    auto deflated = storage::combine(codec, split);
+    CHECK(deflated.is_ok() && deflated->has_value());
+    auto combined = inflated::Batch::try_from(codec, deflated::Batch(**deflated));
+    CHECK(combined.is_ok());
+    CHECK(combined->producer_id == producer_id && combined->producer_epoch == producer_epoch);
+    CHECK(combined->base_sequence == 0 && combined->base_offset == base_offset && combined->attributes == attributes);
+    size_t index = 0;
+    for (const auto &batch : batches)
+        for (const auto &value : batch) {
+            CHECK(index < combined->records.size());
+            const Record &rec = combined->records[index];
+            CHECK(!rec.key.has_value());
+            CHECK(rec.value.has_value() && *rec.value == bytes_of(value.c_str()));
+            CHECK(size_t(rec.offset_delta) == index);
+            index++;
+        }
+    CHECK(index == 12 && combined->records.size() == 12);
+    // batch.rs:690-691, 697-698
+    CHECK(combined->last_offset_delta == 11);
+    CHECK(combined->max_timestamp == 1700000000000 + 5 * 250);
+    CHECK(combined->records[3].timestamp_delta == -250 && combined->records[11].timestamp_delta == -1250);
+    // a member that does not inflate fails the whole combine with its error
+    split[2].attributes = 6;
+    auto bad = storage::combine(codec, split);
+    CHECK(bad.is_err() && bad.error().kind == Error::UnknownCompressionType);
+}
+
+// pg.rs:867-936 on the golden batch and on one with keys, nulls and headers
+static void produce_rows(Codec &codec) {
+    auto d = deflated::Batch::try_from(Bytes(kBatch71, sizeof(kBatch71))).unwrap();
+    auto rows = storage::produce_rows(codec, d, std::nullopt);
+    CHECK(rows.is_ok() && rows->records.size() == 1 && rows->headers.empty());
+    CHECK(rows->records[0].offset == 0 && rows->records[0].timestamp == 1707058170165);
+    CHECK(!rows->records[0].key.has_value() && *rows->records[0].value == bytes_of("def"));
+    inflated::Batch ib;
+    ib.attributes = 0x0110;  // transactional and an unknown bit: the rows carry 0x10
+    ib.base_timestamp = ib.max_timestamp = 5000;
+    ib.last_offset_delta = 2;
+    for (int i = 0; i < 3; i++) {
+        Record r;
+        r.offset_delta = i;
+        r.timestamp_delta = 7 * i - 3;
+        if (i != 1) r.key = bytes_of("key");
+        if (i != 2) r.value = bytes_of(i ? "v" : "value-0");
+        for (int h = 0; h < i; h++) r.headers.push_back(Header{bytes_of("h"), h ? std::nullopt : std::optional<Bytes>(bytes_of("x"))});
+        ib.records.push_back(r);
+    }
+    auto wire = deflated::Batch::try_from(codec, ib).unwrap();
+    rows = storage::produce_rows(codec, wire, int64_t(1000));
+    CHECK(rows.is_ok() && rows->records.size() == 3 && rows->headers.size() == 3);
+    for (int i = 0; i < 3; i++) {
+        const auto &row = rows->records[size_t(i)];
+        CHECK(row.offset == 1000 + i && row.timestamp == 5000 + 7 * i - 3 && row.attributes == 0x10);
+        CHECK(row.key == ib.records[size_t(i)].key && row.value == ib.records[size_t(i)].value);
+    }
+    CHECK(rows->headers[0].offset == 1001 && rows->headers[1].offset == 1002 && rows->headers[2].offset == 1002);
+    CHECK(*rows->headers[1].key == bytes_of("h") && *rows->headers[1].value == bytes_of("x") &&
+          !rows->headers[2].value.has_value());
+    // a timestamp before the epoch: Error::TryFromInt in the PostgreSQL engine, stored by the SQLite one
+    ib.base_timestamp = 2;
+    wire = deflated::Batch::try_from(codec, ib).unwrap();
+    auto neg = storage::produce_rows(codec, wire, std::nullopt, true);
+    CHECK(neg.is_err() && neg.error().kind == Error::TryFromInt);
+    neg = storage::produce_rows(codec, wire, std::nullopt, false);
+    CHECK(neg.is_ok() && neg->records[0].timestamp == -1);
+}
+
 int main(int argc, char **argv) {
     std::string mode = argc > 1 ? argv[1] : "cpu";
     deflated_batch_from_bytes();
@@ -170,6 +281,9 @@ int main(int argc, char **argv) {
         attributes_by_value_and_by_reference(codec);
         records_with_keys_and_headers_round_trip(codec);
         truncated_record_data_is_an_error(codec);
+        combine_empty(codec);
+        combine_batches(codec);
+        produce_rows(codec);
     }
     printf("ok %d checks (%s)\n", checks, mode.c_str());
     return 0;
