@@ -16,11 +16,12 @@
  *   From<deflated::Batch> for Bytes                 src/record/deflated.rs:84-106
  *   records-blob framing                            src/de.rs:701-720, 1056-1093; src/ser.rs:484-489, 521-574
  *
- * and, as operators on the decoded columns, two callers of that path in
+ * and, as operators on the decoded columns, three callers of that path in
  * nisshi-storage:
  *
  *   the produce seam of the SQL engines             nisshi-storage/src/pg.rs:797-943, lite.rs:703-815
  *   combine (the produce queue)                     nisshi-storage/src/batch.rs:661-709
+ *   the fetch seam of the SQL engines               nisshi-storage/src/pg.rs:1875-2052, lite.rs:2765-2980
  *
  * Decoded batches are columns, not Vec<Record>.  Span
  * offsets are relative to the batch's record_data, mirroring the zero-copy
@@ -258,6 +259,63 @@ int nisshi_hip_combine(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_l
                        const uint64_t *batch_off, uint32_t n_batches, const uint32_t *group_off,
                        uint32_t n_groups, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
                        int32_t *group_status, nisshi_totals *totals);
+
+/* ---- the fetch seam of the SQL engines (nisshi-storage/src/pg.rs:1875-2052,
+ * lite.rs:2765-2980).  The reference reads the rows of one topic partition in
+ * offset order and builds deflated batches from them: a new batch where
+ * (attributes, producer_id, producer_epoch) change (pg.rs:1933-1958), each from
+ * inflated::Batch::builder() (nisshi-sans-io/src/record/inflated.rs:311-329) and
+ * one Record::builder() a row (src/record.rs:298-314).  Here the rows are columns,
+ * one entry a row, nullable SQL columns already defaulted as the reference does
+ * (attributes 0, producer_id -1, producer_epoch -1). */
+typedef struct nisshi_fetch_rows {
+    const int64_t *offset;         /* column 0 */
+    const int16_t *attributes;     /* column 1 */
+    const int64_t *timestamp;      /* column 2, milliseconds since the epoch (to_timestamp) */
+    const int64_t *producer_id;    /* column 6 */
+    const int16_t *producer_epoch; /* column 7 */
+    const uint8_t *completed;      /* column 8 (pg.rs:1928-1931); NULL: no such check (lite.rs) */
+    const uint32_t *key_off;       /* column 3 as a span of the payload buffer */
+    const int32_t *key_len;        /* negative: None */
+    const uint32_t *val_off;       /* column 4 */
+    const int32_t *val_len;
+    const uint32_t *hdr_base;      /* n_rows + 1 entries: row i owns headers hdr_base[i] .. hdr_base[i + 1] (header_fetch.sql) */
+    const nisshi_header_span *hdr; /* spans of the payload buffer */
+} nisshi_fetch_rows;
+
+/* Rows to the columns nisshi_hip_encode_dev takes; record r is row r.
+ *   a row with completed == 0 that does not follow its predecessor's offset
+ *     directly ends the fetch: it and the rows after it give no records, though it
+ *     may still open a last, empty batch (pg.rs:1933-1971)
+ *   offset_delta    = i32::try_from(offset - base_offset); a value that does not
+ *     fit fails the fetch: every batch gets NISSHI_TRY_FROM_INT (pg.rs:1973)
+ *   timestamp_delta = timestamp - base_timestamp (pg.rs:1975-1984), wrapping
+ *   length          = the size of the record's body (record.rs:298-314, 363-372)
+ *   a batch takes base_offset, attributes, base_timestamp, producer_id and
+ *     producer_epoch from its first row, last_offset_delta from its last record,
+ *     max_timestamp = now (the builder's default, never set by the fetch),
+ *     partition_leader_epoch -1, magic 2, base_sequence 0; batch_length and crc
+ *     are left 0 (the deflate recomputes them, deflated.rs:392-409)
+ *   no rows give one default batch with base_timestamp = now and producer_epoch 0
+ *     (pg.rs:2050-2052)
+ * The deadline check of the reference (pg.rs:2044) is the caller's choice of
+ * n_rows.  d_out: per-batch arrays of batch_cap entries, per-record arrays of
+ * n_rows entries; its hdr pointer is not used: encode with d_out's pointers,
+ * hdr = d_rows->hdr, d_src = the payload buffer and d_src_data_off = d_out->data_off
+ * (all 0).  n_rows < 2^32.  With n_batches == NULL the call only enqueues work;
+ * otherwise it waits for the stream, stores the number of batches and returns
+ * NISSHI_CAPACITY when that exceeds batch_cap, NISSHI_TRY_FROM_INT when the
+ * fetch failed. */
+int nisshi_hip_fetch_batches_dev(nisshi_hip_ctx *ctx, const nisshi_fetch_rows *d_rows, uint64_t n_rows,
+                                 int64_t now, const nisshi_columns *d_out, uint32_t batch_cap,
+                                 uint32_t *n_batches, void *stream);
+
+/* Host-buffer form: rows and payload in host memory to deflated batches in out
+ * (out_off: batch_cap + 1 entries, *n_batches + 1 of them written). */
+int nisshi_hip_fetch(nisshi_hip_ctx *ctx, const nisshi_fetch_rows *rows, uint64_t n_rows,
+                     const uint8_t *payload, uint64_t payload_len, int64_t now, uint8_t *out,
+                     uint64_t out_cap, uint64_t *out_off, uint32_t batch_cap, uint32_t *n_batches,
+                     nisshi_totals *totals);
 
 /* Page-locked host memory for the host-buffer entry points: blobs and columns
  * in buffers from here move over PCIe by DMA at link speed; any other host

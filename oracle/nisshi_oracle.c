@@ -800,3 +800,122 @@ int no_combine(const uint8_t *const *batches, const size_t *lens, size_t n, uint
     no_records_free(all, total);
     return st;
 }
+
+/* ---- the fetch seam of the SQL engines */
+
+/* inflated::Batch::builder() with the setters the fetch uses (inflated.rs:311-329):
+ * what is not set keeps its default */
+typedef struct {
+    no_deflated_batch hdr;
+    no_record *records;
+    size_t n, cap;
+} fetch_builder;
+
+static void fetch_builder_init(fetch_builder *fb, int64_t now) {
+    memset(fb, 0, sizeof *fb);
+    fb->hdr.base_offset = 0;
+    fb->hdr.partition_leader_epoch = -1;
+    fb->hdr.magic = 2;
+    fb->hdr.attributes = 0;
+    fb->hdr.last_offset_delta = 0;
+    fb->hdr.base_timestamp = now; /* to_timestamp(&SystemTime::now()) */
+    fb->hdr.max_timestamp = now;
+    fb->hdr.producer_id = -1;
+    fb->hdr.producer_epoch = 0;
+    fb->hdr.base_sequence = 0;
+}
+
+/* batch_builder.build().and_then(TryInto::try_into): Record::try_from(Builder)
+ * stores the body size as length (record.rs:298-314), then deflated.rs:392-409 */
+static int fetch_builder_push(fetch_builder *fb, uint8_t *out, size_t out_cap, uint64_t *out_off,
+                              size_t batch_cap, size_t *n_batches) {
+    if (*n_batches >= batch_cap) return NO_CAPACITY;
+    for (size_t i = 0; i < fb->n; i++) fb->records[i].length = (int32_t)no_record_body_size(&fb->records[i]);
+    size_t at = (size_t)out_off[*n_batches], len = 0;
+    int st = no_deflate(&fb->hdr, fb->records, fb->n, out + at, out_cap - at, &len);
+    if (st) return st;
+    out_off[++*n_batches] = at + len;
+    return NO_OK;
+}
+
+static void fetch_builder_clear(fetch_builder *fb) {
+    for (size_t i = 0; i < fb->n; i++) free(fb->records[i].headers);
+    free(fb->records);
+    fb->records = NULL;
+    fb->n = fb->cap = 0;
+}
+
+/* pg.rs:1875-2052 (completed != NULL) and lite.rs:2760-2975 (completed == NULL) */
+int no_fetch(size_t n, const int64_t *offset, const int16_t *attributes, const int64_t *timestamp,
+             const int64_t *producer_id, const int16_t *producer_epoch, const uint8_t *completed,
+             const uint32_t *key_off, const int32_t *key_len, const uint32_t *val_off,
+             const int32_t *val_len, const uint32_t *hdr_base, const uint32_t *hdr_spans,
+             const uint8_t *payload, int64_t now, uint8_t *out, size_t out_cap, uint64_t *out_off,
+             size_t batch_cap, size_t *n_batches) {
+    fetch_builder fb;
+    int st = NO_OK;
+    *n_batches = 0;
+    out_off[0] = 0;
+    fetch_builder_init(&fb, now);
+    if (n == 0) /* pg.rs:2050-2052: an empty batch */
+        return fetch_builder_push(&fb, out, out_cap, out_off, batch_cap, n_batches);
+    fb.hdr.base_offset = offset[0]; /* pg.rs:1878-1909 */
+    fb.hdr.attributes = attributes[0];
+    fb.hdr.base_timestamp = timestamp[0];
+    fb.hdr.producer_id = producer_id[0];
+    fb.hdr.producer_epoch = producer_epoch[0];
+    int have_previous = 0;
+    int64_t previous_offset = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (fb.hdr.attributes != attributes[i] || fb.hdr.producer_id != producer_id[i] ||
+            fb.hdr.producer_epoch != producer_epoch[i]) { /* pg.rs:1933-1958 */
+            st = fetch_builder_push(&fb, out, out_cap, out_off, batch_cap, n_batches);
+            fetch_builder_clear(&fb);
+            if (st) return st;
+            fetch_builder_init(&fb, now);
+            fb.hdr.base_offset = offset[i];
+            fb.hdr.base_timestamp = timestamp[i];
+            fb.hdr.attributes = attributes[i];
+            fb.hdr.producer_id = producer_id[i];
+            fb.hdr.producer_epoch = producer_epoch[i];
+        }
+        /* pg.rs:1965-1971: a record of a transaction still open ends the fetch,
+         * unless it follows its predecessor directly */
+        if (completed && !completed[i] && (!have_previous || previous_offset + 1 != offset[i])) break;
+        int64_t delta = (int64_t)((uint64_t)offset[i] - (uint64_t)fb.hdr.base_offset);
+        if (delta < INT32_MIN || delta > INT32_MAX) { /* i32::try_from, pg.rs:1973 */
+            fetch_builder_clear(&fb);
+            *n_batches = 0;
+            return NO_TRY_FROM_INT;
+        }
+        if (fb.n == fb.cap) {
+            fb.cap = fb.cap ? 2 * fb.cap : 16;
+            fb.records = (no_record *)realloc(fb.records, fb.cap * sizeof(no_record));
+        }
+        no_record *r = &fb.records[fb.n++];
+        memset(r, 0, sizeof *r);
+        r->attributes = 0; /* Record::builder() */
+        r->offset_delta = (int32_t)delta;
+        r->timestamp_delta = (int64_t)((uint64_t)timestamp[i] - (uint64_t)fb.hdr.base_timestamp); /* pg.rs:1975-1984 */
+        r->key.ptr = payload + key_off[i];
+        r->key.len = key_len[i] < 0 ? -1 : key_len[i];
+        r->value.ptr = payload + val_off[i];
+        r->value.len = val_len[i] < 0 ? -1 : val_len[i];
+        r->n_headers = hdr_base[i + 1] - hdr_base[i]; /* pg.rs:2004-2036 */
+        r->headers = r->n_headers ? (no_header *)calloc(r->n_headers, sizeof(no_header)) : NULL;
+        for (size_t j = 0; j < r->n_headers; j++) {
+            const uint32_t *h = hdr_spans + 4 * ((size_t)hdr_base[i] + j);
+            r->headers[j].key.ptr = payload + h[0];
+            r->headers[j].key.len = (int32_t)h[1] < 0 ? -1 : (int32_t)h[1];
+            r->headers[j].value.ptr = payload + h[2];
+            r->headers[j].value.len = (int32_t)h[3] < 0 ? -1 : (int32_t)h[3];
+        }
+        have_previous = 1;
+        previous_offset = offset[i];
+        fb.hdr.last_offset_delta = (int32_t)delta; /* pg.rs:2040-2042 */
+    }
+    st = fetch_builder_push(&fb, out, out_cap, out_off, batch_cap, n_batches); /* pg.rs:2049 */
+    fetch_builder_clear(&fb);
+    if (st) *n_batches = 0;
+    return st;
+}

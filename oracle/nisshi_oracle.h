@@ -251,6 +251,32 @@ int no_produce_rows(const uint8_t *batch, size_t len, int64_t high, int check_ti
 int no_combine(const uint8_t *const *batches, const size_t *lens, size_t n, uint8_t *out,
                size_t out_cap, size_t *out_len, int *is_none);
 
+/* The fetch seam of the SQL engines: the rows of one topic partition, in offset
+ * order, become deflated batches (nisshi-storage/src/pg.rs:1875-2052; lite.rs:2760-2975
+ * is the same without the `completed` column: pass NULL).  One array entry a row,
+ * nullable columns already defaulted as the reference does (attributes 0,
+ * producer_id -1, producer_epoch -1); timestamps in milliseconds (to_timestamp).
+ * A new batch starts where (attributes, producer_id, producer_epoch) change
+ * (pg.rs:1933-1958); a row with completed == 0 that does not follow its
+ * predecessor's offset directly ends the fetch (pg.rs:1965-1971); each record is
+ *   offset_delta    = i32::try_from(offset - base_offset)   (else TRY_FROM_INT for the call)
+ *   timestamp_delta = timestamp - base_timestamp
+ *   length          = the body size (record.rs:298-314), attributes 0
+ * and each batch is inflated::Batch::builder() (inflated.rs:311-329: partition_leader_epoch
+ * -1, magic 2, base_sequence 0, max_timestamp = now) with base_offset, attributes,
+ * base_timestamp, producer_id, producer_epoch of its first row and last_offset_delta
+ * of its last record, deflated (deflated.rs:392-409).  No rows give one empty
+ * default batch (pg.rs:2050-2052).  Spans are (offset, length) into payload, a
+ * negative length is None; row i's headers are hdr_spans[4 * hdr_base[i] .. 4 * hdr_base[i + 1])
+ * as (key_off, key_len, val_off, val_len).  The deadline check of the reference
+ * (pg.rs:2044) is the caller's choice of n. */
+int no_fetch(size_t n, const int64_t *offset, const int16_t *attributes, const int64_t *timestamp,
+             const int64_t *producer_id, const int16_t *producer_epoch, const uint8_t *completed,
+             const uint32_t *key_off, const int32_t *key_len, const uint32_t *val_off,
+             const int32_t *val_len, const uint32_t *hdr_base, const uint32_t *hdr_spans,
+             const uint8_t *payload, int64_t now, uint8_t *out, size_t out_cap, uint64_t *out_off,
+             size_t batch_cap, size_t *n_batches);
+
 #ifdef __cplusplus
 }
 #endif

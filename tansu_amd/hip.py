@@ -24,7 +24,7 @@ EXPORTS = [
     "nisshi_hip_profile_enable", "nisshi_hip_profile_get", "nisshi_hip_profile_name",
     "nisshi_hip_host_alloc", "nisshi_hip_host_free",
     "nisshi_hip_produce_rows_dev", "nisshi_hip_produce_rows", "nisshi_hip_combine_dev",
-    "nisshi_hip_combine",
+    "nisshi_hip_combine", "nisshi_hip_fetch_batches_dev", "nisshi_hip_fetch",
 ]
 
 
@@ -44,6 +44,33 @@ NONE = 10  # NISSHI_NONE
 class CRows(ctypes.Structure):
     """ctypes view of `nisshi_rows`."""
     _fields_ = [(name, ctypes.c_void_p) for name, _, _ in ROW_ARRAYS]
+
+
+# `nisshi_fetch_rows`: (name, dtype, level) with level 1 per row, 3 per row plus one, 2 per header
+FETCH_ARRAYS = [("offset", np.int64, 1), ("attributes", np.int16, 1), ("timestamp", np.int64, 1),
+                ("producer_id", np.int64, 1), ("producer_epoch", np.int16, 1), ("completed", np.uint8, 1),
+                ("key_off", np.uint32, 1), ("key_len", np.int32, 1), ("val_off", np.uint32, 1),
+                ("val_len", np.int32, 1), ("hdr_base", np.uint32, 3), ("hdr", np.uint32, 2)]
+
+
+class CFetchRows(ctypes.Structure):
+    """ctypes view of `nisshi_fetch_rows`."""
+    _fields_ = [(name, ctypes.c_void_p) for name, _, _ in FETCH_ARRAYS]
+
+
+def fetch_rows_host(rows: dict):
+    """`rows`: numpy arrays by the names of FETCH_ARRAYS (`completed` may be None;
+    `hdr` is (n_headers, 4) uint32).  Returns (struct, arrays kept alive)."""
+    keep, c = {}, CFetchRows()
+    for name, dt, _ in FETCH_ARRAYS:
+        v = rows.get(name)
+        if v is None:
+            setattr(c, name, None)
+            continue
+        a = np.ascontiguousarray(v, dtype=dt)
+        keep[name] = a if a.size else np.zeros(4, dtype=dt)
+        setattr(c, name, keep[name].ctypes.data)
+    return c, keep
 
 
 class NisshiError(RuntimeError):
@@ -100,6 +127,10 @@ def load() -> ctypes.CDLL:
                                            ctypes.POINTER(C.CColumns), vp]
     lib.nisshi_hip_combine.argtypes = [vp, vp, u64, vp, u32, vp, u32, vp, u64, vp, vp,
                                        ctypes.POINTER(Totals)]
+    lib.nisshi_hip_fetch_batches_dev.argtypes = [vp, ctypes.POINTER(CFetchRows), u64, ctypes.c_int64,
+                                                 ctypes.POINTER(C.CColumns), u32, ctypes.POINTER(u32), vp]
+    lib.nisshi_hip_fetch.argtypes = [vp, ctypes.POINTER(CFetchRows), u64, vp, u64, ctypes.c_int64, vp, u64,
+                                     vp, u32, ctypes.POINTER(u32), ctypes.POINTER(Totals)]
     lib.nisshi_hip_profile_enable.argtypes = [vp, i32]
     lib.nisshi_hip_profile_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     lib.nisshi_hip_profile_name.argtypes = [i32]
@@ -310,6 +341,52 @@ class Codec:
             self.ctx, ctypes.byref(cols.c), n_batches, n_slots, cols.hdr_cap, d_group_off.data_ptr(),
             n_groups, ctypes.byref(sink.c), self._stream()))
         return sink
+
+    def fetch_rows_to_device(self, rows: dict):
+        """Copy fetch rows (see fetch_rows_host) to the GPU; returns (struct, tensors kept alive)."""
+        import torch
+        keep, c = {}, CFetchRows()
+        for name, dt, _ in FETCH_ARRAYS:
+            v = rows.get(name)
+            if v is None:
+                setattr(c, name, None)
+                continue
+            a = np.ascontiguousarray(v, dtype=dt).reshape(-1)
+            if a.size == 0:
+                a = np.zeros(4, dtype=dt)
+            keep[name] = torch.from_numpy(a.view(np.dtype(f"i{a.dtype.itemsize}")).copy()).to(self.device)
+            setattr(c, name, keep[name].data_ptr())
+        return c, keep
+
+    def fetch_batches_dev(self, d_rows: "CFetchRows", d_hdr, n_rows: int, now: int, batch_cap: int,
+                          sync: bool = True):
+        """Batches of the SQL engines' fetch seam from rows on the GPU.  Returns
+        (columns ready for encode_dev, number of batches or None)."""
+        out = DeviceColumns(batch_cap, n_rows, 0, self.device)
+        if d_hdr is not None:
+            out.t["hdr"] = d_hdr
+            out.c.hdr = d_hdr.data_ptr()
+        n = ctypes.c_uint32(0)
+        self._check(self.lib.nisshi_hip_fetch_batches_dev(
+            self.ctx, ctypes.byref(d_rows), n_rows, now, ctypes.byref(out.c), batch_cap,
+            ctypes.byref(n) if sync else None, self._stream()))
+        return out, (n.value if sync else None)
+
+    def fetch(self, rows: dict, payload: bytes, now: int, batch_cap: int = 64, out_cap: Optional[int] = None):
+        """The fetch seam over host buffers: returns (list of deflated batches, totals)."""
+        c, keep = fetch_rows_host(rows)
+        n_rows = len(rows["offset"])
+        arr = np.frombuffer(bytes(payload), dtype=np.uint8)
+        n_hdr = int(keep["hdr_base"][n_rows]) if n_rows else 0
+        if out_cap is None:
+            out_cap = len(arr) + 61 * batch_cap + 64 * n_rows + 32 * n_hdr + 1024
+        out = np.zeros(out_cap, dtype=np.uint8)
+        out_off = np.zeros(batch_cap + 1, dtype=np.uint64)
+        n, totals = ctypes.c_uint32(0), Totals()
+        self._check(self.lib.nisshi_hip_fetch(
+            self.ctx, ctypes.byref(c), n_rows, arr.ctypes.data if len(arr) else None, len(arr), now,
+            out.ctypes.data, out_cap, out_off.ctypes.data, batch_cap, ctypes.byref(n), ctypes.byref(totals)))
+        return [out[int(out_off[b]):int(out_off[b + 1])].tobytes() for b in range(n.value)], totals
 
     def crc32c_dev(self, d_data, length: int, offset: int = 0) -> int:
         out = ctypes.c_uint32(0)

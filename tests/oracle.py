@@ -78,6 +78,7 @@ def _load():
     lib.no_produce_rows.argtypes = [vp, sz, i64, ctypes.c_int, sz, sz, vp] + [vp] * 11 + \
         [ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.no_combine.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int)]
+    lib.no_fetch.argtypes = [sz] + [vp] * 13 + [i64, vp, sz, vp, sz, ctypes.POINTER(sz)]
     return lib
 
 
@@ -210,3 +211,36 @@ def combine(batches):
     if st or none.value:
         return st, None
     return st, out[:out_len.value].tobytes()
+
+
+FETCH_FIELDS = [("offset", np.int64), ("attributes", np.int16), ("timestamp", np.int64),
+                ("producer_id", np.int64), ("producer_epoch", np.int16), ("completed", np.uint8),
+                ("key_off", np.uint32), ("key_len", np.int32), ("val_off", np.uint32),
+                ("val_len", np.int32), ("hdr_base", np.uint32), ("hdr", np.uint32)]
+
+
+def fetch(rows: dict, payload: bytes, now: int, batch_cap: int = 64):
+    """The fetch seam (pg.rs:1875-2052; `completed` None: lite.rs:2765-2980) over
+    rows given as arrays.  Returns (status, list of deflated batches)."""
+    n = len(rows["offset"])
+    keep = []
+    ptrs = []
+    for name, dt in FETCH_FIELDS:
+        v = rows.get(name)
+        if v is None:
+            ptrs.append(None)
+            continue
+        a = np.ascontiguousarray(v, dtype=dt)
+        if a.size == 0:
+            a = np.zeros(4, dtype=dt)
+        keep.append(a)
+        ptrs.append(a.ctypes.data)
+    pl = np.frombuffer(bytes(payload), dtype=np.uint8) if len(payload) else np.zeros(1, dtype=np.uint8)
+    n_hdr = int(rows["hdr_base"][n]) if n else 0
+    cap = len(pl) + 61 * batch_cap + 64 * n + 32 * n_hdr + 1024
+    out = np.zeros(cap, dtype=np.uint8)
+    out_off = np.zeros(batch_cap + 1, dtype=np.uint64)
+    nb = ctypes.c_size_t(0)
+    st = LIB.no_fetch(n, *ptrs, pl.ctypes.data, now, out.ctypes.data, cap, out_off.ctypes.data,
+                      batch_cap, ctypes.byref(nb))
+    return st, [out[int(out_off[b]):int(out_off[b + 1])].tobytes() for b in range(nb.value)]

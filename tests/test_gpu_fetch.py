@@ -1,0 +1,130 @@
+"""Parity of the fetch-seam operator (nisshi-storage/src/pg.rs:1875-2052,
+lite.rs:2765-2980) with its CPU restatement, through the C ABI.  Bit-exact: the
+deflated batches must be the same bytes."""
+import numpy as np
+import pytest
+
+import oracle
+from fetch_cases import CASES, NOW, make_rows
+from tansu_amd import columns as C, hip
+from util import header_slots
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def codec():
+    c = hip.Codec(0)
+    yield c
+    c.close()
+
+
+def fetch_dev(codec, rows, payload, batch_cap=64):
+    """Rows on the GPU -> columns -> encode; returns (status, batches)."""
+    import torch
+    n = len(rows["offset"])
+    d_rows, keep = codec.fetch_rows_to_device(rows)
+    try:
+        cols, nb = codec.fetch_batches_dev(d_rows, keep.get("hdr"), n, NOW, batch_cap)
+    except hip.NisshiError as e:
+        return e.status, []
+    pl = np.frombuffer(payload, dtype=np.uint8)
+    d_payload = torch.zeros(len(pl) + 16, dtype=torch.uint8, device=codec.device)
+    if len(pl):
+        d_payload[:len(pl)].copy_(torch.from_numpy(pl.copy()))
+    cap = len(pl) + 61 * nb + 64 * n + 32 * len(rows["hdr"]) + 1024
+    out = torch.zeros(cap + 16, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(nb + 1, dtype=torch.int64, device=codec.device)
+    t = codec.encode_dev(cols, nb, d_payload, cols.t["data_off"], out, cap, out_off)
+    off = out_off.cpu().numpy()
+    raw = out[:t.out_bytes].cpu().numpy().tobytes()
+    return C.OK, [raw[int(off[b]):int(off[b + 1])] for b in range(nb)]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_cases_device(codec, name):
+    kw = dict(CASES[name])
+    rows, payload = make_rows(kw.pop("n"), seed=len(name), **kw)
+    st, want = oracle.fetch(rows, payload, NOW)
+    gst, got = fetch_dev(codec, rows, payload)
+    assert gst == st
+    assert got == want
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_cases_host(codec, name):
+    kw = dict(CASES[name])
+    rows, payload = make_rows(kw.pop("n"), seed=len(name), **kw)
+    st, want = oracle.fetch(rows, payload, NOW)
+    try:
+        got, totals = codec.fetch(rows, payload, NOW)
+        gst = C.OK
+    except hip.NisshiError as e:
+        gst, got = e.status, []
+    assert gst == st
+    assert got == want
+
+
+def test_no_rows(codec):
+    rows, payload = make_rows(0)
+    st, want = oracle.fetch(rows, payload, NOW)
+    assert fetch_dev(codec, rows, payload) == (C.OK, want)
+    got, _ = codec.fetch(rows, payload, NOW)
+    assert got == want
+
+
+def test_capacity(codec):
+    rows, payload = make_rows(30, seed=1, change_every=3)
+    st, _ = fetch_dev(codec, rows, payload, batch_cap=4)
+    assert st == C.CAPACITY
+    st, want = oracle.fetch(rows, payload, NOW, batch_cap=10)
+    assert fetch_dev(codec, rows, payload, batch_cap=10) == (st, want)
+
+
+@pytest.mark.parametrize("kw", [dict(n=20000, change_every=997, gap_rate=0.2),
+                                dict(n=30000, change_every=4100, open_rate=0.0002, gap_rate=0.5),
+                                dict(n=9000, change_every=2, headers=3)])
+def test_many_rows(codec, kw):
+    # several blocks of the batch scan, batches that straddle them
+    kw = dict(kw)
+    rows, payload = make_rows(kw.pop("n"), seed=5, **kw)
+    st, want = oracle.fetch(rows, payload, NOW, batch_cap=8192)
+    gst, got = fetch_dev(codec, rows, payload, batch_cap=8192)
+    assert gst == st == C.OK
+    assert got == want
+
+
+def test_produce_then_fetch_round_trip(codec):
+    """Rows written by the produce seam and read back by the fetch seam carry the
+    same records: the batch's records at offsets high .. high + n - 1."""
+    from test_gpu_storage import header_batches
+    batch = header_batches()[0]
+    blob = batch
+    off = np.array([0, len(batch)], dtype=np.uint64)
+    high = np.array([4200], dtype=np.int64)
+    g, prow, totals = codec.produce_rows(blob, off, high, True)
+    n = int(g["record_count"][0])
+    base = int(g["data_off"][0])
+    hdr = np.stack([g["hkey_off"] + base, g["hkey_len"].view(np.uint32), g["hval_off"] + base,
+                    g["hval_len"].view(np.uint32)], axis=1).astype(np.uint32)
+    counts = g["rhdr_count"][:n].astype(np.int64)
+    hb = np.concatenate([[0], np.cumsum(counts)])
+    slots = header_slots(g["rhdr_base"][:n], counts)   # a record's headers are contiguous from its slot
+    rows = dict(offset=prow["offset"][:n], attributes=np.full(n, g["attributes"][0], dtype=np.int16),
+                timestamp=prow["timestamp"][:n], producer_id=np.full(n, g["producer_id"][0]),
+                producer_epoch=np.full(n, g["producer_epoch"][0], dtype=np.int16), completed=np.ones(n),
+                key_off=g["key_off"][:n] + base, key_len=g["key_len"][:n],
+                val_off=g["val_off"][:n] + base, val_len=g["val_len"][:n],
+                hdr_base=hb, hdr=hdr[slots])
+    got, _ = codec.fetch(rows, blob, NOW)
+    assert len(got) == 1
+    st, cols, nr, nh = oracle.decode_columns(got[0], np.array([0, len(got[0])], dtype=np.uint64), True)
+    assert st == C.OK and int(cols["base_offset"][0]) == 4200
+    back = C.records_of_batch(cols, 0, got[0])
+    st, c0, _, _ = oracle.decode_columns(batch, off, True)
+    orig = C.records_of_batch(c0, 0, batch)
+    assert len(back) == len(orig) == n
+    first_ts = orig[0].timestamp_delta
+    for a, b in zip(orig, back):
+        assert (a.key, a.value, a.headers) == (b.key, b.value, b.headers)
+        assert a.timestamp_delta - first_ts == b.timestamp_delta

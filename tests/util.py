@@ -92,7 +92,7 @@ def body_size(rec: C.Record) -> int:
     def octets(b):
         return oracle.varint_size(-1 if b is None else len(b)) + (0 if b is None else len(b))
     n = 1 + oracle.varint_size(rec.timestamp_delta, "i64") + oracle.varint_size(rec.offset_delta)
-    n += octets(rec.key) + octets(rec.value) + oracle.varint_size(len(rec.headers), "u32")
+    n += octets(rec.key) + octets(rec.value) + oracle.varint_size(len(rec.headers))
     for h in rec.headers:
         n += octets(h.key) + octets(h.value)
     return n
