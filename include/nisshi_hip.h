@@ -16,12 +16,13 @@
  *   From<deflated::Batch> for Bytes                 src/record/deflated.rs:84-106
  *   records-blob framing                            src/de.rs:701-720, 1056-1093; src/ser.rs:484-489, 521-574
  *
- * and, as operators on the decoded columns, three callers of that path in
+ * and, as operators on the decoded columns, four callers of that path in
  * nisshi-storage:
  *
  *   the produce seam of the SQL engines             nisshi-storage/src/pg.rs:797-943, lite.rs:703-815
  *   combine (the produce queue)                     nisshi-storage/src/batch.rs:661-709
  *   the fetch seam of the SQL engines               nisshi-storage/src/pg.rs:1875-2052, lite.rs:2765-2980
+ *   log compaction                                  nisshi-storage/src/slate/storage.rs:283-312
  *
  * Decoded batches are columns, not Vec<Record>.  Span
  * offsets are relative to the batch's record_data, mirroring the zero-copy
@@ -54,7 +55,8 @@ enum {
     NISSHI_CAPACITY = 7,            /* an output array is too small */
     NISSHI_DEVICE_ERROR = 8,        /* a HIP call failed; see nisshi_hip_last_error */
     NISSHI_INVALID_ARGUMENT = 9,
-    NISSHI_NONE = 10                /* combine of no batches: Ok(None), nisshi-storage/src/batch.rs:666-668 */
+    NISSHI_NONE = 10                /* no batch: combine of no batches (Ok(None), nisshi-storage/src/batch.rs:666-668);
+                                       compaction leaves nothing to write for this batch */
 };
 
 /* Decoded records are columns, grouped so that the fields the decoder produces
@@ -316,6 +318,48 @@ int nisshi_hip_fetch(nisshi_hip_ctx *ctx, const nisshi_fetch_rows *rows, uint64_
                      const uint8_t *payload, uint64_t payload_len, int64_t now, uint8_t *out,
                      uint64_t out_cap, uint64_t *out_off, uint32_t batch_cap, uint32_t *n_batches,
                      nisshi_totals *totals);
+
+/* ---- log compaction of a topic partition (nisshi-storage/src/slate/storage.rs:283-312
+ * with inflated::Batch::compact and keys, nisshi-sans-io/src/record/inflated.rs:213-275).
+ * d_cols: the partition's batches decoded (by value) from d_blob, oldest first.
+ * Working from the newest batch to the oldest, a record is dropped when its key
+ * appears in a newer batch or later in its own batch; records without a key
+ * stay; control batches (attributes bit 5) are neither compacted nor do their
+ * keys count (storage.rs:291-293).  As in the reference, retain() goes by the
+ * value of offset_delta (inflated.rs:262-264): a keyed record also stays when a
+ * record of its batch that stays as the last of its key has the same offset_delta.
+ * d_group (or NULL): a partition id per batch; keys are only compared within a
+ * group, so several partitions can be compacted by one call.
+ *
+ * d_out receives the compacted partition: per-batch arrays of n_batches entries,
+ * per-record arrays of n_slots entries (the records that stay, packed in order);
+ * its hdr pointer is not used: a record's headers stay where they are in d_cols->hdr.
+ * Batch headers are kept (the batch structure is preserved, inflated.rs:229-231);
+ * record_count and rec_base are new; in a batch that lost records every record's
+ * length becomes the size of its body, as into_builder().build() makes it
+ * (inflated.rs:266-268, record.rs:298-314).  d_removed[b]: the count the
+ * reference reports (Compaction::records).  d_action[b]: 0 nothing removed, the
+ * stored batch stays (storage.rs:299-301); 1 rewritten; 2 no record left, the
+ * batch is deleted (storage.rs:305-307).  d_out->status[b] is NISSHI_OK for a
+ * rewritten batch and NISSHI_NONE for the other two, so that nisshi_hip_encode_dev
+ * on d_out (with hdr = d_cols->hdr, d_src = d_blob, d_src_data_off = d_out->data_off)
+ * deflates exactly the batches to write back (storage.rs:309-317); a batch that
+ * did not decode keeps its status and takes no part (the reference fails the
+ * whole compaction on it, storage.rs:289).  With totals == NULL the call only
+ * enqueues work; otherwise it waits and totals->n_records is the number of
+ * records that stay. */
+int nisshi_hip_compact_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, const nisshi_columns *d_cols,
+                           uint32_t n_batches, uint64_t n_slots, const uint32_t *d_group,
+                           const nisshi_columns *d_out, uint32_t *d_removed, int32_t *d_action,
+                           nisshi_totals *totals, void *stream);
+
+/* Host-buffer form: inflate, compact and deflate in one call.  out receives the
+ * rewritten batches (out_off: n_batches + 1 offsets; a batch that is not
+ * rewritten has no bytes); removed, action, status: one entry a batch. */
+int nisshi_hip_compact(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
+                       const uint64_t *batch_off, uint32_t n_batches, const uint32_t *group,
+                       uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t *removed,
+                       int32_t *action, int32_t *status, nisshi_totals *totals);
 
 /* Page-locked host memory for the host-buffer entry points: blobs and columns
  * in buffers from here move over PCIe by DMA at link speed; any other host

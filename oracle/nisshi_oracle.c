@@ -919,3 +919,163 @@ int no_fetch(size_t n, const int64_t *offset, const int16_t *attributes, const i
     if (st) *n_batches = 0;
     return st;
 }
+
+/* ---- log compaction */
+
+/* BTreeSet<Bytes> / BTreeMap<Bytes, i32> of the reference, as a chained hash map
+ * (only membership and the value of a key matter here, not the order) */
+typedef struct key_node {
+    const uint8_t *ptr;
+    size_t len;
+    int32_t value;
+    struct key_node *next;
+} key_node;
+
+typedef struct {
+    key_node **slot;
+    size_t n_slots;
+} key_map;
+
+static void key_map_init(key_map *m, size_t expect) {
+    m->n_slots = 64;
+    while (m->n_slots < 2 * expect) m->n_slots *= 2;
+    m->slot = (key_node **)calloc(m->n_slots, sizeof(key_node *));
+}
+
+static void key_map_free(key_map *m) {
+    for (size_t i = 0; i < m->n_slots; i++)
+        for (key_node *k = m->slot[i]; k;) {
+            key_node *next = k->next;
+            free(k);
+            k = next;
+        }
+    free(m->slot);
+}
+
+static key_node **key_map_find(key_map *m, const uint8_t *ptr, size_t len) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < len; i++) h = (h ^ ptr[i]) * 1099511628211ull;
+    key_node **at = &m->slot[h & (m->n_slots - 1)];
+    while (*at && !((*at)->len == len && memcmp((*at)->ptr, ptr, len) == 0)) at = &(*at)->next;
+    return at;
+}
+
+/* insert: returns 1 when the key was there already (its value is replaced) */
+static int key_map_insert(key_map *m, const uint8_t *ptr, size_t len, int32_t value) {
+    key_node **at = key_map_find(m, ptr, len);
+    if (*at) {
+        (*at)->value = value;
+        return 1;
+    }
+    key_node *k = (key_node *)calloc(1, sizeof *k);
+    k->ptr = ptr;
+    k->len = len;
+    k->value = value;
+    *at = k;
+    return 0;
+}
+
+static int cmp_i32(const void *a, const void *b) {
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* inflated::Batch::compact, inflated.rs:235-275.  Returns the number of records
+ * the reference counts as removed and marks the records retain() keeps. */
+static size_t compact_batch(const no_record *recs, size_t n, key_map *head, uint8_t *keep) {
+    key_map last; /* last_delta_offset_for_key */
+    key_map_init(&last, n);
+    size_t removed = 0;
+    for (size_t i = 0; i < n; i++) { /* :239-253 */
+        if (recs[i].key.len < 0) continue;
+        if (*key_map_find(head, recs[i].key.ptr, (size_t)recs[i].key.len)) {
+            removed++;
+            continue;
+        }
+        if (key_map_insert(&last, recs[i].key.ptr, (size_t)recs[i].key.len, recs[i].offset_delta)) removed++;
+    }
+    for (size_t i = 0; i < n; i++) keep[i] = 1;
+    if (removed > 0) { /* :257-264: retained by the VALUE of offset_delta */
+        int32_t *vals = (int32_t *)malloc((n + 1) * sizeof(int32_t)); /* delta_offsets_to_retain */
+        size_t nv = 0;
+        for (size_t s = 0; s < last.n_slots; s++)
+            for (key_node *k = last.slot[s]; k; k = k->next) vals[nv++] = k->value;
+        qsort(vals, nv, sizeof(int32_t), cmp_i32);
+        for (size_t i = 0; i < n; i++)
+            if (recs[i].key.len >= 0)
+                keep[i] = bsearch(&recs[i].offset_delta, vals, nv, sizeof(int32_t), cmp_i32) != NULL;
+        free(vals);
+    }
+    key_map_free(&last);
+    return removed;
+}
+
+/* slate/storage.rs:283-312 over the batches of one partition, oldest first */
+int no_compact_partition(const uint8_t *const *batches, const size_t *lens, size_t n, uint8_t *out,
+                         size_t out_cap, uint64_t *out_off, int64_t *removed, int32_t *action) {
+    key_map head;
+    size_t total_keys = 0;
+    no_deflated_batch *d = (no_deflated_batch *)calloc(n + 1, sizeof *d);
+    no_record **recs = (no_record **)calloc(n + 1, sizeof *recs);
+    size_t *counts = (size_t *)calloc(n + 1, sizeof *counts);
+    int st = NO_OK;
+    for (size_t b = 0; b < n && st == NO_OK; b++) { /* InflatedBatch::try_from(deflated.clone())? */
+        st = inflate_by_value(batches[b], lens[b], &d[b], &recs[b], &counts[b]);
+        total_keys += counts[b];
+    }
+    key_map_init(&head, total_keys);
+    size_t at = 0;
+    /* the reference walks newest to oldest; outputs are laid out oldest first, so
+     * the bytes of each rewritten batch are produced into a scratch area first */
+    uint8_t **piece = (uint8_t **)calloc(n + 1, sizeof *piece);
+    size_t *piece_len = (size_t *)calloc(n + 1, sizeof *piece_len);
+    for (size_t r = 0; r < n && st == NO_OK; r++) {
+        size_t b = n - 1 - r;
+        removed[b] = 0;
+        action[b] = NO_COMPACT_UNCHANGED;
+        if (d[b].attributes & 0x20) continue; /* BatchAttribute.control, storage.rs:291-293 */
+        uint8_t *keep = (uint8_t *)malloc(counts[b] + 1);
+        size_t gone = compact_batch(recs[b], counts[b], &head, keep); /* :296 */
+        for (size_t i = 0; i < counts[b]; i++) /* head.extend(keys), :295, 297 */
+            if (recs[b][i].key.len >= 0)
+                key_map_insert(&head, recs[b][i].key.ptr, (size_t)recs[b][i].key.len, 0);
+        removed[b] = (int64_t)gone;
+        if (gone) {
+            size_t m = 0;
+            no_record *kept = (no_record *)calloc(counts[b] + 1, sizeof *kept);
+            for (size_t i = 0; i < counts[b]; i++)
+                if (keep[i]) kept[m++] = recs[b][i];
+            if (m == 0) {
+                action[b] = NO_COMPACT_DELETED; /* storage.rs:305-307 */
+            } else {
+                /* into_builder().build() (inflated.rs:266-268): lengths become body sizes;
+                 * then compaction.batch.try_into() (storage.rs:309) */
+                for (size_t i = 0; i < m; i++) kept[i].length = (int32_t)no_record_body_size(&kept[i]);
+                size_t cap = 61;
+                for (size_t i = 0; i < m; i++) cap += no_record_size(&kept[i]);
+                piece[b] = (uint8_t *)malloc(cap);
+                st = no_deflate(&d[b], kept, m, piece[b], cap, &piece_len[b]);
+                action[b] = NO_COMPACT_REWRITTEN;
+            }
+            free(kept);
+        }
+        free(keep);
+    }
+    out_off[0] = 0;
+    for (size_t b = 0; b < n; b++) {
+        if (st == NO_OK && piece_len[b]) {
+            if (at + piece_len[b] > out_cap) st = NO_CAPACITY;
+            else memcpy(out + at, piece[b], piece_len[b]), at += piece_len[b];
+        }
+        out_off[b + 1] = at;
+        free(piece[b]);
+        no_records_free(recs[b], counts[b]);
+    }
+    key_map_free(&head);
+    free(piece);
+    free(piece_len);
+    free(d);
+    free(recs);
+    free(counts);
+    return st;
+}

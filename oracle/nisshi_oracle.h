@@ -277,6 +277,24 @@ int no_fetch(size_t n, const int64_t *offset, const int16_t *attributes, const i
              const uint8_t *payload, int64_t now, uint8_t *out, size_t out_cap, uint64_t *out_off,
              size_t batch_cap, size_t *n_batches);
 
+/* Log compaction of one topic partition (nisshi-storage/src/slate/storage.rs:283-312
+ * with inflated::Batch::compact and keys, nisshi-sans-io/src/record/inflated.rs:213-275).
+ * batches: the partition's deflated batches, oldest first.  Newest to oldest, a
+ * record is dropped when its key appears in a newer batch or later in its own
+ * batch; records without a key stay; control batches (attributes bit 5) are
+ * neither compacted nor do their keys count.  As in the reference, retain() goes
+ * by the VALUE of offset_delta: a keyed record also stays when another record of
+ * its batch that stays as the last of its key has the same offset_delta.
+ * removed[b] is the count the reference reports (Compaction::records); action[b]:
+ *   UNCHANGED  nothing removed (or a control batch): the stored batch stays
+ *   DELETED    no record left (storage.rs:305-307)
+ *   REWRITTEN  the batch rebuilt by into_builder().build() (every length becomes the
+ *              body size, record.rs:298-314) and deflated (deflated.rs:392-409): its
+ *              bytes are out[out_off[b] .. out_off[b + 1]) */
+enum { NO_COMPACT_UNCHANGED = 0, NO_COMPACT_REWRITTEN = 1, NO_COMPACT_DELETED = 2 };
+int no_compact_partition(const uint8_t *const *batches, const size_t *lens, size_t n, uint8_t *out,
+                         size_t out_cap, uint64_t *out_off, int64_t *removed, int32_t *action);
+
 #ifdef __cplusplus
 }
 #endif

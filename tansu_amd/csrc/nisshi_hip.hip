@@ -1134,4 +1134,5 @@ __global__ void crc_buffer_finish_kernel(const uint8_t *data, uint64_t len, uint
 #include "encode.inc"
 #include "storage.inc"
 #include "fetch.inc"
+#include "compact.inc"
 #include "api.inc"

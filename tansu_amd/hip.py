@@ -25,6 +25,7 @@ EXPORTS = [
     "nisshi_hip_host_alloc", "nisshi_hip_host_free",
     "nisshi_hip_produce_rows_dev", "nisshi_hip_produce_rows", "nisshi_hip_combine_dev",
     "nisshi_hip_combine", "nisshi_hip_fetch_batches_dev", "nisshi_hip_fetch",
+    "nisshi_hip_compact_dev", "nisshi_hip_compact",
 ]
 
 
@@ -131,6 +132,9 @@ def load() -> ctypes.CDLL:
                                                  ctypes.POINTER(C.CColumns), u32, ctypes.POINTER(u32), vp]
     lib.nisshi_hip_fetch.argtypes = [vp, ctypes.POINTER(CFetchRows), u64, vp, u64, ctypes.c_int64, vp, u64,
                                      vp, u32, ctypes.POINTER(u32), ctypes.POINTER(Totals)]
+    lib.nisshi_hip_compact_dev.argtypes = [vp, vp, ctypes.POINTER(C.CColumns), u32, u64, vp,
+                                           ctypes.POINTER(C.CColumns), vp, vp, ctypes.POINTER(Totals), vp]
+    lib.nisshi_hip_compact.argtypes = [vp, vp, u64, vp, u32, vp, vp, u64, vp, vp, vp, vp, ctypes.POINTER(Totals)]
     lib.nisshi_hip_profile_enable.argtypes = [vp, i32]
     lib.nisshi_hip_profile_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     lib.nisshi_hip_profile_name.argtypes = [i32]
@@ -387,6 +391,46 @@ class Codec:
             self.ctx, ctypes.byref(c), n_rows, arr.ctypes.data if len(arr) else None, len(arr), now,
             out.ctypes.data, out_cap, out_off.ctypes.data, batch_cap, ctypes.byref(n), ctypes.byref(totals)))
         return [out[int(out_off[b]):int(out_off[b + 1])].tobytes() for b in range(n.value)], totals
+
+    def compact_dev(self, d_blob, cols: DeviceColumns, n_batches: int, n_slots: int, d_group=None,
+                    sync: bool = True):
+        """Log compaction of decoded batches (oldest first).  Returns (compacted columns
+        sharing the header array of `cols`, removed tensor, action tensor, totals or None)."""
+        import torch
+        out = DeviceColumns(n_batches, n_slots, 0, self.device)
+        out.t["hdr"] = cols.t["hdr"]
+        out.c.hdr = cols.t["hdr"].data_ptr()
+        out.hdr_cap = cols.hdr_cap
+        removed = torch.zeros(max(n_batches, 1), dtype=torch.int32, device=self.device)
+        action = torch.zeros(max(n_batches, 1), dtype=torch.int32, device=self.device)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_compact_dev(
+            self.ctx, d_blob.data_ptr(), ctypes.byref(cols.c), n_batches, n_slots,
+            d_group.data_ptr() if d_group is not None else None, ctypes.byref(out.c), removed.data_ptr(),
+            action.data_ptr(), ctypes.byref(totals) if sync else None, self._stream()))
+        return out, removed, action, (totals if sync else None)
+
+    def compact(self, blob: bytes, batch_off, group=None, out_cap: Optional[int] = None):
+        """Inflate, compact and deflate batches held in host bytes (oldest first).  Returns
+        (rewritten bytes or None per batch, removed, action, status, totals)."""
+        arr = np.frombuffer(bytes(blob), dtype=np.uint8)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+        n_b = len(off) - 1
+        grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
+        out_cap = len(arr) + 64 if out_cap is None else out_cap
+        out = np.zeros(max(out_cap, 1), dtype=np.uint8)
+        out_off = np.zeros(n_b + 1, dtype=np.uint64)
+        removed = np.zeros(max(n_b, 1), dtype=np.uint32)
+        action = np.zeros(max(n_b, 1), dtype=np.int32)
+        status = np.zeros(max(n_b, 1), dtype=np.int32)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_compact(
+            self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data, n_b,
+            grp.ctypes.data if grp is not None else None, out.ctypes.data, out_cap, out_off.ctypes.data,
+            removed.ctypes.data, action.ctypes.data, status.ctypes.data, ctypes.byref(totals)))
+        pieces = [out[int(out_off[b]):int(out_off[b + 1])].tobytes() if action[b] == 1 else None
+                  for b in range(n_b)]
+        return pieces, removed[:n_b], action[:n_b], status[:n_b], totals
 
     def crc32c_dev(self, d_data, length: int, offset: int = 0) -> int:
         out = ctypes.c_uint32(0)

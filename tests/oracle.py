@@ -78,6 +78,7 @@ def _load():
     lib.no_produce_rows.argtypes = [vp, sz, i64, ctypes.c_int, sz, sz, vp] + [vp] * 11 + \
         [ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.no_combine.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int)]
+    lib.no_compact_partition.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp]
     lib.no_fetch.argtypes = [sz] + [vp] * 13 + [i64, vp, sz, vp, sz, ctypes.POINTER(sz)]
     return lib
 
@@ -244,3 +245,27 @@ def fetch(rows: dict, payload: bytes, now: int, batch_cap: int = 64):
     st = LIB.no_fetch(n, *ptrs, pl.ctypes.data, now, out.ctypes.data, cap, out_off.ctypes.data,
                       batch_cap, ctypes.byref(nb))
     return st, [out[int(out_off[b]):int(out_off[b + 1])].tobytes() for b in range(nb.value)]
+
+
+UNCHANGED, REWRITTEN, DELETED = 0, 1, 2
+
+
+def compact_partition(batches):
+    """Log compaction of one partition's deflated batches, oldest first (slate/
+    storage.rs:283-312).  Returns (status, removed np.int64[n], action np.int32[n],
+    list of rewritten batches' bytes or None)."""
+    bufs = [np.frombuffer(bytes(b), dtype=np.uint8) if len(b) else np.zeros(0, dtype=np.uint8)
+            for b in batches]
+    n = len(bufs)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    lens = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in bufs])
+    cap = sum(len(b) for b in bufs) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    removed = np.zeros(max(n, 1), dtype=np.int64)
+    action = np.zeros(max(n, 1), dtype=np.int32)
+    st = LIB.no_compact_partition(ptrs, lens, n, out.ctypes.data, cap, out_off.ctypes.data,
+                                  removed.ctypes.data, action.ctypes.data)
+    pieces = [out[int(out_off[b]):int(out_off[b + 1])].tobytes() if action[b] == REWRITTEN else None
+              for b in range(n)]
+    return st, removed[:n], action[:n], pieces
