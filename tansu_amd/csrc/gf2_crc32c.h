@@ -219,23 +219,40 @@ __device__ inline uint32_t crc_rows(const uint8_t *base, uint64_t grid, uint64_t
 
 // A wave's pass over one batch: rows are fetched in order with coalesced 16-byte
 // loads, folded into the CRC accumulator and copied raw into a ring of the last
-// kRingRows rows in LDS, from which the same wave then parses records.  The
+// ring rows in LDS, from which the same wave then parses records.  The
 // batch is read from HBM once.  The caller loads the rows it will need next into
 // registers (load), works on what is in the ring while they arrive, and then
 // moves them in (take_loaded): both within one pass of its loop, so that no load
 // is in flight across a loop edge.
-constexpr int kRingRows = 8;
-constexpr int kRingBytes = kRingRows * kRowBytes;
+// The ring comes in two sizes: eight rows let four waves a SIMD run, which suits
+// batches of a few KiB; twelve rows hold a round of 64 records of up to 160 bytes
+// (eight rows hold 42 of C2's 143-byte records) at three waves a SIMD, which suits
+// batches of 64 KiB and more.
 constexpr int kRingGuard = 64;  // the ring's first bytes again, so a window may run past the end
-constexpr int kRingWords = (kRingBytes + kRingGuard) / 4;
-constexpr int kAhead = 8;
+template <int kRows>
+struct RingCfg {
+    static constexpr int kRingRows = kRows;
+    static constexpr int kRingBytes = kRows * kRowBytes;
+    static constexpr int kRingWords = (kRingBytes + kRingGuard) / 4;
+    static constexpr int kAhead = kRows == 8 ? 8 : kRows - 1;  // rows asked for a round ahead
+    static constexpr bool kPow2 = (kRows & (kRows - 1)) == 0;
+    __device__ static __forceinline__ uint32_t slot_of(uint32_t row) {
+        return kPow2 ? row & (uint32_t)(kRows - 1) : row % (uint32_t)kRows;
+    }
+    __device__ static __forceinline__ uint32_t wrap(uint32_t at) {
+        return kPow2 ? at & (uint32_t)(kRingBytes - 1) : at % (uint32_t)kRingBytes;
+    }
+};
 // pointers into LDS keep their address space, so that accesses are ds_read /
 // ds_write and not flat instructions
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u128;
 
+template <int kRows>
 struct BatchStream {
+    typedef RingCfg<kRows> Cfg;
+    static constexpr int kRingBytes = Cfg::kRingBytes, kAhead = Cfg::kAhead;
     // Offsets are relative to `grid`, the 16-byte boundary at or below the first
     // byte: the stream handles at most 4 GiB.
     uint32_t lo, hi;          // the bytes [lo, hi) are the data; lo < 16
@@ -284,7 +301,7 @@ struct BatchStream {
     // Row r into the ring (raw: bytes outside [lo, hi) are never parsed) and into
     // the CRC.  The accumulator starts at zero, and folding zero gives zero.
     __device__ __forceinline__ void take(u32x4 v, uint32_t r) {
-        uint32_t slot = r & (kRingRows - 1);
+        uint32_t slot = Cfg::slot_of(r);
         *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4) = v;
         if (slot == 0 && lane < kRingGuard / 16) *(lds_u128 *)(ring + kRingBytes / 4 + lane * 4) = v;
         uint32_t nx[4] = {v.x, v.y, v.z, v.w};
@@ -296,7 +313,7 @@ struct BatchStream {
     // value 0xFFFFFFFF).  The fold is linear, so this is an XOR into the
     // accumulator, before the next row is folded.
     __device__ __forceinline__ void fix_edge(uint32_t r) {
-        uint32_t slot = r & (kRingRows - 1);
+        uint32_t slot = Cfg::slot_of(r);
         u32x4 raw = *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4);
         uint64_t addr = (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
 #pragma unroll

@@ -586,14 +586,15 @@ struct Shape {
 // an LDS read that is not aligned stalls the LDS pipeline of the whole CU for
 // tens of cycles, and the walk makes a dozen reads a round in every wave.  (A
 // read may run up to eight bytes past the ring's end, into its guard.)
+template <int kRows>
 struct RingView {
     const lds_u32 *ring;
     __device__ __forceinline__ uint32_t read32(uint32_t at) const {
-        const lds_u32 *p = ring + ((at & (kRingBytes - 1)) >> 2);
+        const lds_u32 *p = ring + (RingCfg<kRows>::wrap(at) >> 2);
         return __builtin_amdgcn_alignbyte(p[1], p[0], at & 3);
     }
     __device__ __forceinline__ uint64_t read64(uint32_t at) const {
-        const lds_u32 *p = ring + ((at & (kRingBytes - 1)) >> 2);
+        const lds_u32 *p = ring + (RingCfg<kRows>::wrap(at) >> 2);
         uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
         uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, at & 3);
         uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, at & 3);
@@ -612,7 +613,8 @@ struct RingView {
 // attributes byte), 2 offset delta, 3 key, 4 value, 5 header count, then a key
 // and a value per header.  The bytes of every varint belong to the shape, except
 // that of the two deltas only the widths do.
-__device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView ring, uint32_t at0, uint32_t size) {
+template <int kRows>
+__device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring, uint32_t at0, uint32_t size) {
     lds_u128 *htab = tab + kShapeChecks;
     lds_u128 *out = htab + kShapeHdrs;
     uint32_t p = 0;  // offset in the record
@@ -693,15 +695,17 @@ __device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView ring, uint32
 // the shape in hand, learning the first one's shape when it does not fit, and
 // emits the records that fit.  On kWalkGlobal *k_out and *pos_out say where the
 // slower walk resumes.
+template <int kRows>
 __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c, HeaderRuns &runs,
-                                             BatchStream &stream, lds_u128 *tab, int lane,
+                                             BatchStream<kRows> &stream, lds_u128 *tab, int lane,
                                              uint32_t *k_out, uint32_t *pos_out) {
     uint32_t count = uni(c.record_count[b]);
     uint64_t rbase = uni(c.rec_base[b]);
     uint32_t data_len = uni(c.data_len[b]);
     // the record data's offset in the stream: data_off - (batch start + 21) + stream.lo
     uint32_t bias = 40 + stream.lo;
-    RingView ring{stream.ring};
+    constexpr int kRingBytes = RingCfg<kRows>::kRingBytes, kAhead = RingCfg<kRows>::kAhead;
+    RingView<kRows> ring{stream.ring};
     lds_u128 *htab = tab + kShapeChecks;
     Shape shape;
     shape.n_checks = 0;
@@ -936,11 +940,12 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
 // wave cannot stream them fast enough) and their records from slow_walk_kernel.
 constexpr uint32_t kBigChunks = 8;
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_fused_kernel(const uint8_t *blob,
+template <int kRows, int kWaves>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
                                                           uint64_t hdr_cap, const CrcTables *t) {
-    __shared__ __attribute__((aligned(16))) uint32_t ring[kRingWords];
+    __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
     __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
     uint32_t b = blockIdx.x;
     int lane = threadIdx.x;
@@ -952,7 +957,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (lane == 0) c.status[b] = NISSHI_CAPACITY;
         do_walk = false;
     }
-    BatchStream stream;
+    BatchStream<kRows> stream;
     uint64_t lo = batch_off[b] + 21;
     stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
     if (do_walk) {
