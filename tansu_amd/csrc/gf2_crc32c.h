@@ -168,6 +168,12 @@ __device__ inline uint32_t crc_row_residue(const uint32_t (&a)[4], int lane, con
     return wave_xor(gf_mulmod(c, t->lane_weight[lane]));
 }
 
+// pointers into LDS keep their address space, so that accesses are ds_read /
+// ds_write and not flat instructions
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u128;
+
 // Byte mask of a little-endian word at absolute address `addr`: keep the bytes in [lo, hi).
 __device__ __forceinline__ uint32_t byte_mask(uint64_t addr, uint64_t lo, uint64_t hi) {
     uint32_t m = 0xFFFFFFFFu;
@@ -184,9 +190,28 @@ __device__ __forceinline__ uint32_t byte_mask(uint64_t addr, uint64_t lo, uint64
 __device__ inline uint32_t crc_rows(const uint8_t *base, uint64_t grid, uint64_t lo, uint64_t hi,
                                     uint64_t first4, uint32_t row0, uint32_t row1, int lane,
                                     const CrcTables *t) {
-    uint32_t acc[4] = {0, 0, 0, 0};
-    bool started = false;
-    for (uint32_t r = row0; r < row1; r++) {
+    uint32_t acc[4] = {0, 0, 0, 0};  // folding a zero accumulator gives the row itself
+    // rows that lie wholly inside the data and past its first four bytes need no
+    // masks: eight of them are loaded before the first is folded, so that a wave
+    // keeps 8 KiB in flight
+    constexpr uint32_t kBurst = 8;
+    uint32_t full_rows = hi > grid ? (uint32_t)((hi - grid) / kRowBytes) : 0;
+    uint32_t plain_from = first4 < grid + kRowBytes ? 1 : 0, plain_to = row1 < full_rows ? row1 : full_rows;
+    const uint8_t *lane_base = base + grid + (uint64_t)lane * 16;
+    for (uint32_t r = row0; r < row1;) {
+        if (r >= plain_from && r + kBurst <= plain_to) {
+            u32x4 q[kBurst];
+#pragma unroll
+            for (uint32_t j = 0; j < kBurst; j++)
+                q[j] = *reinterpret_cast<const u32x4 *>(lane_base + (uint64_t)(r + j) * kRowBytes);
+#pragma unroll
+            for (uint32_t j = 0; j < kBurst; j++) {
+                uint32_t nx[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+                crc_fold_row(acc, nx, lane);
+            }
+            r += kBurst;
+            continue;
+        }
         uint64_t addr = grid + (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
         uint32_t nx[4] = {0, 0, 0, 0};
         if (addr + 16 > lo && addr < hi) {
@@ -205,13 +230,8 @@ __device__ inline uint32_t crc_rows(const uint8_t *base, uint64_t grid, uint64_t
 #pragma unroll
             for (int i = 0; i < 4; i++) nx[i] ^= byte_mask(addr + 4 * i, first4, first4 + 4);
         }
-        if (started) {
-            crc_fold_row(acc, nx, lane);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = nx[i];
-            started = true;
-        }
+        crc_fold_row(acc, nx, lane);
+        r++;
     }
     return crc_row_residue(acc, lane, t);
 }
@@ -243,11 +263,6 @@ struct RingCfg {
         return kPow2 ? at & (uint32_t)(kRingBytes - 1) : at % (uint32_t)kRingBytes;
     }
 };
-// pointers into LDS keep their address space, so that accesses are ds_read /
-// ds_write and not flat instructions
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x4 lds_u128;
 
 template <int kRows>
 struct BatchStream {
