@@ -151,6 +151,35 @@ def main():
         "kernels_ms": {k: v[0] / v[1] for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
     }
 
+    # ---- the re-encode leg (deflated::Batch::try_from(inflated::Batch)), outside the
+    # timed region: columns + payload -> wire bytes, which must equal the input
+    out = torch.zeros(in_bytes + 64, dtype=torch.uint8, device=dev)
+    out_off = torch.zeros(n_batches + 1, dtype=torch.int64, device=dev)
+    te = codec.encode_dev(cols, n_batches, d_blob, cols.t["data_off"], out, in_bytes, out_off)
+    exact = te.out_bytes == in_bytes and bool(torch.equal(out[:in_bytes], d_blob[:in_bytes]))
+    codec.profile(True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codec.encode_dev(cols, n_batches, d_blob, cols.t["data_off"], out, in_bytes, out_off, sync=False)
+    torch.cuda.synchronize(dev)
+    enc_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    ekt = codec.kernel_times()
+    codec.profile(False)
+    payload = int((cols.t["rkey"][:n_records, 3].clamp(min=0).sum() + cols.t["rval"][:n_records, 1].clamp(min=0).sum()
+                   + (cols.t["hdr"][:n_headers, 1].clamp(min=0).sum() + cols.t["hdr"][:n_headers, 3].clamp(min=0).sum()
+                      if n_headers else 0)).item())
+    enc_bytes = (algo_bytes - in_bytes) + payload + in_bytes   # columns and payload read, wire bytes written
+    result["reencode"] = {
+        "bit_exact": exact,
+        "ms_per_step": enc_ms,
+        "records_per_s": n_records / (enc_ms * 1e-3),
+        "algorithmic_bytes": enc_bytes,
+        "algorithmic_gbs": enc_bytes / (enc_ms * 1e-3) / 1e9,
+        "roundtrip_records_per_s": n_records / ((step_ms + enc_ms) * 1e-3),
+        "kernels_ms": {k: v[0] / v[1] for k, v in sorted(ekt.items(), key=lambda kv: -kv[1][0])},
+    }
+
     if args.with_copies:
         # the host-buffer entry point: H2D of the blob, the kernels, D2H of the columns;
         # once from ordinary host memory and once from page-locked buffers

@@ -1,7 +1,7 @@
 """Copy the summaries of a scratch/profile_round.sh run from gpurun_out/ into
 profiles/ (tracked) and refresh profiles/traffic.json, which bench.py reads for
 `roofline.traffic`.  usage: python scratch/collect_profiles.py <tag> <name> [workload]"""
-import glob, json, os, shutil, sys
+import glob, json, os, re, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "c2"
@@ -14,7 +14,9 @@ shutil.copy(os.path.join(src, "trace_bench.json"), os.path.join(dst, f"{name}_be
 summary = json.load(open(os.path.join(src, "summary.json")))
 tpath = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-traffic[workload] = {k: v["total"] for k, v in summary["traffic_bytes_per_launch"].items()}
+# kernel names as bench.py knows them: no "void", no template arguments
+traffic[workload] = {re.sub(r"^void ", "", re.sub(r"<.*>$", "", k)): v["total"]
+                     for k, v in summary["traffic_bytes_per_launch"].items()}
 traffic["_source"] = traffic.get("_source", {})
 traffic["_source"][workload] = f"{name}_summary.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate passes, bytes per launch"
 json.dump(traffic, open(tpath, "w"), indent=1)
