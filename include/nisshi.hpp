@@ -630,5 +630,122 @@ inline Result<Rows> produce_rows(Codec &codec, const record::deflated::Batch &de
     return out;
 }
 
+// One row of record_fetch_pg.sql as the fetch reads it (pg.rs:1877-1931, 1960-1996)
+// with the rows header_fetch.sql gives for its offset (pg.rs:2004-2036).
+struct FetchRow {
+    int64_t offset = 0;                    // column 0
+    std::optional<int16_t> attributes;     // column 1, None -> 0
+    int64_t timestamp = 0;                 // column 2 through to_timestamp: milliseconds since the epoch
+    std::optional<Bytes> key, value;       // columns 3, 4
+    std::optional<int64_t> producer_id;    // column 6, None -> -1
+    std::optional<int16_t> producer_epoch; // column 7, None -> -1
+    bool completed = true;                 // column 8
+    std::vector<record::Header> headers;
+};
+
+// pg.rs:1875-2052 (with_completed) and lite.rs:2765-2980 (without): the rows of
+// one topic partition, in offset order, to deflated batches.  `now` stands for the
+// SystemTime::now() of inflated::Batch::builder() (inflated.rs:311-329).  An offset
+// delta that does not fit i32 is Error::TryFromInt (pg.rs:1973).  One device call.
+inline Result<std::vector<record::deflated::Batch>> fetch(Codec &codec, const std::vector<FetchRow> &rows,
+                                                          int64_t now, bool with_completed = true) {
+    using record::deflated::Batch;
+    const size_t n = rows.size();
+    std::vector<int64_t> offset(n + 1), timestamp(n + 1), producer_id(n + 1);
+    std::vector<int16_t> attributes(n + 1), producer_epoch(n + 1);
+    std::vector<uint8_t> completed(n + 1), payload;
+    std::vector<uint32_t> key_off(n + 1), val_off(n + 1), hdr_base(n + 2, 0);
+    std::vector<int32_t> key_len(n + 1), val_len(n + 1);
+    std::vector<nisshi_header_span> hdr;
+    auto put = [&payload](const std::optional<Bytes> &b, uint32_t &off, int32_t &len) {
+        off = uint32_t(payload.size());
+        len = b ? int32_t(b->len()) : -1;
+        if (b) payload.insert(payload.end(), b->data(), b->data() + b->len());
+    };
+    size_t n_batches = 1;
+    for (size_t i = 0; i < n; i++) {
+        const FetchRow &r = rows[i];
+        offset[i] = r.offset;
+        attributes[i] = r.attributes.value_or(0);
+        timestamp[i] = r.timestamp;
+        producer_id[i] = r.producer_id.value_or(-1);
+        producer_epoch[i] = r.producer_epoch.value_or(-1);
+        completed[i] = r.completed ? 1 : 0;
+        put(r.key, key_off[i], key_len[i]);
+        put(r.value, val_off[i], val_len[i]);
+        for (const record::Header &h : r.headers) {
+            nisshi_header_span sp{};
+            put(h.key, sp.key_off, sp.key_len);
+            put(h.value, sp.val_off, sp.val_len);
+            hdr.push_back(sp);
+        }
+        hdr_base[i + 1] = uint32_t(hdr.size());
+        if (i && (attributes[i] != attributes[i - 1] || producer_id[i] != producer_id[i - 1] ||
+                  producer_epoch[i] != producer_epoch[i - 1]))
+            n_batches++;
+    }
+    hdr.push_back(nisshi_header_span{});
+    nisshi_fetch_rows fr{offset.data(), attributes.data(), timestamp.data(), producer_id.data(),
+                         producer_epoch.data(), with_completed ? completed.data() : nullptr,
+                         key_off.data(), key_len.data(), val_off.data(), val_len.data(), hdr_base.data(), hdr.data()};
+    std::vector<uint8_t> out(payload.size() + 61 * n_batches + 64 * n + 32 * hdr.size() + 1024);
+    std::vector<uint64_t> out_off(n_batches + 1, 0);
+    uint32_t got = 0;
+    nisshi_totals totals{};
+    int st = nisshi_hip_fetch(codec.ctx(), &fr, n, payload.data(), payload.size(), now, out.data(), out.size(),
+                              out_off.data(), uint32_t(n_batches), &got, &totals);
+    if (st) return Error::from_status(st);
+    std::vector<Batch> batches;
+    for (uint32_t b = 0; b < got; b++) {
+        auto d = Batch::try_from(Bytes(out.data() + out_off[b], size_t(out_off[b + 1] - out_off[b])));
+        if (d.is_err()) return d.error();
+        batches.push_back(std::move(*d));
+    }
+    return batches;
+}
+
+// What log compaction does with one stored batch (slate/storage.rs:299-317).
+struct Compaction {
+    enum Action { Unchanged, Rewritten, Deleted } action = Unchanged;
+    size_t records = 0;                           // Compaction::records: what the reference counts as removed
+    std::optional<record::deflated::Batch> batch; // Rewritten: the batch to put back
+};
+
+// slate/storage.rs:283-312 with inflated::Batch::compact and keys (inflated.rs:213-275)
+// over the batches of one topic partition, oldest first: a record goes when its
+// key appears in a newer batch or later in its own; records without a key and
+// control batches stay.  A batch that does not inflate gives its error.  One device call.
+inline Result<std::vector<Compaction>> compact(Codec &codec, const std::vector<record::deflated::Batch> &batches) {
+    using record::deflated::Batch;
+    const size_t n = batches.size();
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> off(n + 1, 0);
+    for (size_t b = 0; b < n; b++) {
+        Bytes e = batches[b].into_bytes();
+        blob.insert(blob.end(), e.data(), e.data() + e.len());
+        off[b + 1] = blob.size();
+    }
+    std::vector<uint8_t> out(blob.size() + 64);
+    std::vector<uint64_t> out_off(n + 1, 0);
+    std::vector<uint32_t> removed(n + 1, 0);
+    std::vector<int32_t> action(n + 1, 0), status(n + 1, 0);
+    nisshi_totals totals{};
+    int st = nisshi_hip_compact(codec.ctx(), blob.data(), blob.size(), off.data(), uint32_t(n), nullptr, out.data(),
+                                out.size(), out_off.data(), removed.data(), action.data(), status.data(), &totals);
+    if (st) return Error::from_status(st);
+    std::vector<Compaction> result(n);
+    for (size_t b = 0; b < n; b++) {
+        if (status[b] != NISSHI_OK && status[b] != NISSHI_NONE) return Error::from_status(status[b], batches[b].attributes & 7);
+        result[b].records = removed[b];
+        result[b].action = action[b] == 1 ? Compaction::Rewritten : action[b] == 2 ? Compaction::Deleted : Compaction::Unchanged;
+        if (action[b] == 1) {
+            auto d = Batch::try_from(Bytes(out.data() + out_off[b], size_t(out_off[b + 1] - out_off[b])));
+            if (d.is_err()) return d.error();
+            result[b].batch = std::move(*d);
+        }
+    }
+    return result;
+}
+
 }  // namespace storage
 }  // namespace nisshi

@@ -270,6 +270,95 @@ static void produce_rows(Codec &codec) {
     CHECK(neg.is_ok() && neg->records[0].timestamp == -1);
 }
 
+// pg.rs:1875-2052: rows to batches; the record of record.rs:478-523 (value "def", length 9)
+static void fetch_rows(Codec &codec) {
+    const int64_t now = 1700000123456;
+    auto none = storage::fetch(codec, {}, now);
+    CHECK(none.is_ok() && none->size() == 1);  // pg.rs:2050-2052: the default batch
+    CHECK((*none)[0].record_count == 0 && (*none)[0].base_timestamp == now && (*none)[0].max_timestamp == now &&
+          (*none)[0].producer_id == -1 && (*none)[0].producer_epoch == 0 && (*none)[0].base_sequence == 0 &&
+          (*none)[0].partition_leader_epoch == -1 && (*none)[0].magic == 2 && (*none)[0].batch_length == 49);
+    std::vector<storage::FetchRow> rows(5);
+    for (int i = 0; i < 5; i++) {
+        rows[size_t(i)].offset = 40 + i;
+        rows[size_t(i)].timestamp = 9000 + 10 * i;
+        rows[size_t(i)].value = bytes_of("def");
+        if (i >= 3) rows[size_t(i)].producer_id = 77, rows[size_t(i)].producer_epoch = int16_t(2);
+    }
+    rows[1].key = bytes_of("k");
+    rows[1].headers.push_back(Header{bytes_of("h"), std::nullopt});
+    auto got = storage::fetch(codec, rows, now);
+    CHECK(got.is_ok() && got->size() == 2);
+    const deflated::Batch &a = (*got)[0], &b = (*got)[1];
+    CHECK(a.base_offset == 40 && a.record_count == 3 && a.last_offset_delta == 2 && a.base_timestamp == 9000 &&
+          a.producer_id == -1 && a.producer_epoch == -1 && a.max_timestamp == now);
+    CHECK(b.base_offset == 43 && b.record_count == 2 && b.last_offset_delta == 1 && b.base_timestamp == 9030 &&
+          b.producer_id == 77 && b.producer_epoch == 2);
+    const uint8_t first[] = {18, 0, 0, 0, 1, 6, 100, 101, 102, 0};  // record.rs:478-523
+    CHECK(a.record_data.len() > sizeof(first) && !memcmp(a.record_data.data(), first, sizeof(first)));
+    auto ia = inflated::Batch::try_from(codec, deflated::Batch(a)).unwrap();
+    CHECK(ia.records[1].key == rows[1].key && ia.records[1].headers.size() == 1 && ia.records[1].offset_delta == 1 &&
+          ia.records[1].timestamp_delta == 10 && ia.records[2].length == 9);
+    // pg.rs:1965-1971: an open transaction's row that does not follow its predecessor ends the fetch
+    rows[2].completed = false;
+    got = storage::fetch(codec, rows, now);
+    CHECK(got.is_ok() && got->size() == 2 && (*got)[0].record_count == 3);  // adjacent offsets: it continues
+    rows[2].offset = 50;
+    got = storage::fetch(codec, rows, now);
+    CHECK(got.is_ok() && got->size() == 1 && (*got)[0].record_count == 2 && (*got)[0].last_offset_delta == 1);
+    got = storage::fetch(codec, rows, now, false);  // lite.rs: no such check
+    CHECK(got.is_ok() && got->size() == 2 && (*got)[0].record_count == 3);
+    rows[2].completed = true;
+    rows[2].offset = 40 + (int64_t(1) << 32);  // pg.rs:1973
+    auto bad = storage::fetch(codec, rows, now);
+    CHECK(bad.is_err() && bad.error().kind == Error::TryFromInt);
+}
+
+static deflated::Batch keyed_batch(Codec &codec, int64_t base_offset,
+                                   const std::vector<std::pair<const char *, const char *>> &kv) {
+    inflated::Batch ib;
+    ib.base_offset = base_offset;
+    ib.last_offset_delta = int32_t(kv.size()) - 1;
+    int32_t od = 0;
+    for (const auto &p : kv) {
+        Record r;
+        r.offset_delta = od++;
+        if (p.first) r.key = bytes_of(p.first);
+        r.value = bytes_of(p.second);
+        ib.records.push_back(r);
+    }
+    return deflated::Batch::try_from(codec, ib).unwrap();
+}
+
+// inflated.rs:664-790, the head given as a newer batch holding those keys
+static void compact_batches(Codec &codec) {
+    auto newer = keyed_batch(codec, 100, {{"k1", "x"}, {"k2", "x"}});
+    // compact_noop_without_duplicates
+    auto r = storage::compact(codec, {keyed_batch(codec, 0, {{"k1", "v1"}, {"k2", "v2"}})});
+    CHECK(r.is_ok() && r->size() == 1 && (*r)[0].records == 0 && (*r)[0].action == storage::Compaction::Unchanged);
+    // compact_within_batch_keeps_last_occurrence_per_key
+    r = storage::compact(codec, {keyed_batch(codec, 5, {{"k1", "v1"}, {"k2", "v2"}, {"k1", "v3"}})});
+    CHECK(r.is_ok() && (*r)[0].records == 1 && (*r)[0].action == storage::Compaction::Rewritten);
+    auto kept = inflated::Batch::try_from(codec, deflated::Batch(*(*r)[0].batch)).unwrap();
+    CHECK(kept.records.size() == 2 && kept.records[0].offset_delta == 1 && *kept.records[0].key == bytes_of("k2") &&
+          kept.records[1].offset_delta == 2 && *kept.records[1].value == bytes_of("v3"));
+    CHECK(kept.base_offset == 5 && kept.last_offset_delta == 2);
+    // compact_drops_keys_in_head
+    r = storage::compact(codec, {keyed_batch(codec, 0, {{"k1", "v1"}, {"k2", "v2"}}), newer});
+    CHECK(r.is_ok() && (*r)[0].records == 2 && (*r)[0].action == storage::Compaction::Deleted && (*r)[1].records == 0);
+    // compact_retains_keyless_records
+    r = storage::compact(codec, {keyed_batch(codec, 0, {{nullptr, "v0"}, {"k1", "v1"}, {"k1", "v2"}})});
+    CHECK(r.is_ok() && (*r)[0].records == 1);
+    kept = inflated::Batch::try_from(codec, deflated::Batch(*(*r)[0].batch)).unwrap();
+    CHECK(kept.records.size() == 2 && kept.records[0].offset_delta == 0 && !kept.records[0].key.has_value() &&
+          kept.records[1].offset_delta == 2 && *kept.records[1].key == bytes_of("k1"));
+    // compact_retains_keyless_when_all_keyed_records_drop
+    r = storage::compact(codec, {keyed_batch(codec, 0, {{nullptr, "v0"}, {"k1", "v1"}}), newer});
+    CHECK(r.is_ok() && (*r)[0].records == 1 && (*r)[0].action == storage::Compaction::Rewritten);
+    kept = inflated::Batch::try_from(codec, deflated::Batch(*(*r)[0].batch)).unwrap();
+    CHECK(kept.records.size() == 1 && kept.records[0].offset_delta == 0 && !kept.records[0].key.has_value());
+}
+
 int main(int argc, char **argv) {
     std::string mode = argc > 1 ? argv[1] : "cpu";
     deflated_batch_from_bytes();
@@ -284,6 +373,8 @@ int main(int argc, char **argv) {
         combine_empty(codec);
         combine_batches(codec);
         produce_rows(codec);
+        fetch_rows(codec);
+        compact_batches(codec);
     }
     printf("ok %d checks (%s)\n", checks, mode.c_str());
     return 0;
