@@ -447,6 +447,16 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
         uint32_t m = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
         uint32_t found = 0, my_start = 0, my_size = 0, my_used = 0;
         int32_t my_len = 0;
+        // Touch where the round after this one will look, so that its lines are on
+        // their way from HBM while this round is parsed (the rounds of one wave run
+        // one after the other, each would otherwise start with a cold miss).
+        uint32_t touched = 0;
+        {
+            uint64_t ahead = (uint64_t)pos + (uint64_t)(m + (uint32_t)lane) * S;
+            typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
+            if (ahead + 4 <= rd.len)
+                touched = *(gbl_u32 *)((reinterpret_cast<uintptr_t>(rd.data) + ahead) & ~uintptr_t(3));
+        }
         while (found < m) {
             uint32_t lanes = m - found;
             uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
@@ -552,6 +562,7 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
         if (__any(live && (!ok || p != end))) return kWalkExact;
         if (live) store_record(c, rbase + k, (uint32_t)lane, f, slot);
         k += m;
+        asm volatile("" ::"v"(touched));  // the touch is waited for here, a round after it was issued
     }
     return kWalkDone;
 }

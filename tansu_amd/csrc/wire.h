@@ -96,36 +96,42 @@ __device__ __forceinline__ bool fast_varlong(uint32_t lo, uint32_t &used, int64_
 struct Reader {
     const uint8_t *data;
     uint32_t len;
-    const lds_u32 *ring;
-    uint32_t ring_bias, ring_mask;
-    uint32_t win_lo, win_hi;
+    // The 24 bytes last loaded, from a 4-byte boundary on: the fields of a record's
+    // head are a few bytes apart, and each would otherwise cost a memory round
+    // trip of its own.  Every lane keeps its own window.
+    uint64_t q0, q1, q2;
+    uintptr_t win;  // address of the window's first byte; 0: none
 
     __device__ __forceinline__ Reader(const uint8_t *data_, uint32_t len_)
-        : data(data_), len(len_), ring(nullptr), ring_bias(0), ring_mask(0), win_lo(0), win_hi(0) {}
+        : data(data_), len(len_), q0(0), q1(0), q2(0), win(0) {}
+
+    // Six aligned words from the one that holds `p`.  As in window64, no load
+    // touches a word that holds no byte of the data.
+    __device__ __forceinline__ void refill(uintptr_t p) {
+        uintptr_t last = (reinterpret_cast<uintptr_t>(data) + len - 1) & ~uintptr_t(3);
+        uintptr_t a0 = p & ~uintptr_t(3);
+        a0 = a0 <= last ? a0 : last;
+        typedef __attribute__((address_space(1))) const uint32_t gbl_u32;  // global, not flat
+        uint32_t d[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            uintptr_t a = a0 + 4 * i <= last ? a0 + 4 * i : last;
+            d[i] = *(gbl_u32 *)a;
+        }
+        q0 = ((uint64_t)d[1] << 32) | d[0];
+        q1 = ((uint64_t)d[3] << 32) | d[2];
+        q2 = ((uint64_t)d[5] << 32) | d[4];
+        win = a0;
+    }
 
     // eight bytes starting at pos (pos < len)
-    __device__ __forceinline__ uint64_t get64(uint32_t pos) const {
-        if (pos >= win_lo && pos + 8 <= win_hi) {
-            typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-            typedef __attribute__((address_space(3))) const u64_unaligned lds_u64;
-            typedef __attribute__((address_space(3))) const uint8_t lds_u8;
-            return *(lds_u64 *)((lds_u8 *)ring + ((pos + ring_bias) & ring_mask));
-        }
-        return window64(data, pos, len);
-    }
-
-    // Unchecked reads of the ring: `at` = position + ring_bias, all bytes staged.
-    __device__ __forceinline__ uint32_t ring32(uint32_t at) const {
-        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-        typedef __attribute__((address_space(3))) const u32_unaligned lds_u32u;
-        typedef __attribute__((address_space(3))) const uint8_t lds_u8;
-        return *(lds_u32u *)((lds_u8 *)ring + (at & ring_mask));
-    }
-    __device__ __forceinline__ uint64_t ring64(uint32_t at) const {
-        typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-        typedef __attribute__((address_space(3))) const u64_unaligned lds_u64;
-        typedef __attribute__((address_space(3))) const uint8_t lds_u8;
-        return *(lds_u64 *)((lds_u8 *)ring + (at & ring_mask));
+    __device__ __forceinline__ uint64_t get64(uint32_t pos) {
+        uintptr_t p = reinterpret_cast<uintptr_t>(data) + pos;
+        if (win == 0 || p < win || p + 8 > win + 24) refill(p);
+        uint32_t o = (uint32_t)(p - win);  // 0 .. 16
+        uint64_t lo = o < 8 ? q0 : o < 16 ? q1 : q2, hi = o < 8 ? q1 : q2;  // o == 16: the last eight, no shift
+        uint32_t sh = (o & 7) * 8;
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
     }
 
     __device__ __forceinline__ int varint(uint32_t &pos, int32_t &out) {
