@@ -190,7 +190,7 @@ def patch_crc(blob: np.ndarray, batch_off: np.ndarray, crc: np.ndarray) -> None:
         blob[starts + k] = be[:, k]
 
 
-# ---- the workloads named in BASELINE.json ------------------------------------
+# ---- the named benchmark workloads ---------------------------------------------
 
 C1_SHAPE = Shape(key_len=-1, val_len=100, n_headers=0)
 C2_SHAPE = Shape(key_len=16, val_len=64, n_headers=2, hkey_len=8, hval_len=16)

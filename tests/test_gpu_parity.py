@@ -312,7 +312,7 @@ def test_empty_call(codec):
 
 @pytest.mark.parametrize("name", ["c2", "c3"])
 def test_full_size_properties(codec, name):
-    """At BASELINE.json's sizes the oracle is too slow to run in a test, so check
+    """At the full benchmark sizes the oracle is too slow to run in a test, so check
     what the domain guarantees: every CRC matches after patching with the GPU's own
     CRC (itself checked against the oracle on a sample of batches), record and
     header totals, arithmetic structure of the decoded columns, and the

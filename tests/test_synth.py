@@ -1,5 +1,5 @@
 """The synthetic generator produces batches the CPU restatement accepts, with the
-sizes BASELINE.json's configurations call for."""
+sizes the benchmark configurations call for."""
 import numpy as np
 
 import oracle
