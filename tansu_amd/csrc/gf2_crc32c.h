@@ -381,6 +381,17 @@ struct BatchStream {
         if (target > rows) target = rows;
 #pragma nounroll
         while (next_row < target) {
+            if (next_row >= 1 && next_row + 8 <= target && next_row + 8 < rows) {
+                // eight rows that are not the first or the last: all loaded before the first is taken
+                u32x4 q[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    q[j] = *reinterpret_cast<const u32x4 *>(lane_ptr + (uint64_t)(next_row + j) * kRowBytes);
+#pragma unroll
+                for (int j = 0; j < 8; j++) take(q[j], next_row + j);
+                next_row += 8;
+                continue;
+            }
             take(fetch(next_row), next_row);
             if (edge(next_row)) fix_edge(next_row);
             next_row++;

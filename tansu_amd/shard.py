@@ -20,8 +20,32 @@ def shard_seed(seed: int, rank: int) -> int:
     return seed + 7919 * rank
 
 
-def make_shard(workload: str, scale: float, rank: int):
+C4_PARTITIONS = 1024        # the mixed workload: topic-partitions in all, 64 batches each
+C4_PARTITIONS_PER_GPU = 128  # what a GPU of an eight-GPU node holds of them
+
+
+def mixed_shard(scale: float, rank: int, world: int):
+    """The mixed workload's partitions of one rank, laid out as one blob: partition
+    p lives on device p mod 8 as on an eight-GPU node, and a job of fewer ranks
+    holds the partitions of its first `world` devices (the same work a GPU, so
+    that rates at 1, 2, 4 and 8 GPUs compare)."""
+    import numpy as np
+    per_gpu = max(5, int(C4_PARTITIONS_PER_GPU * scale))
+    only = [rank + 8 * j for j in range(per_gpu)]
+    parts = synth.mixed_partitions(C4_PARTITIONS, 64, only=only)
+    blob = np.concatenate([p[0] for p in parts])
+    off, base = [np.zeros(1, dtype=np.uint64)], 0
+    for b, o, _, _ in parts:
+        off.append(np.asarray(o[1:], dtype=np.uint64) + np.uint64(base))
+        base += len(b)
+    off = np.concatenate(off)
+    return None, blob, off, sum(p[2] for p in parts), sum(p[3] for p in parts), len(off) - 1
+
+
+def make_shard(workload: str, scale: float, rank: int, world: int = 1):
     """(shape, blob, batch_off, n_records, n_headers, n_batches) of one rank."""
+    if workload == "c4":
+        return mixed_shard(scale, rank, world)
     shape, counts, seed = synth.config(workload, scale)
     blob, off, n_records, n_headers = synth.make_batches(shape, counts, shard_seed(seed, rank))
     return shape, blob, off, n_records, n_headers, len(counts)

@@ -213,9 +213,10 @@ def config(name: str, scale: float = 1.0):
     raise ValueError(name)
 
 
-def mixed_partitions(n_partitions: int, batches_each: int, seed: int = SEED_BASE + 4):
+def mixed_partitions(n_partitions: int, batches_each: int, seed: int = SEED_BASE + 4, only=None):
     """C4: partition p draws its shape from five kinds by p mod 5.  Returns a list
-    of (blob, batch_off, n_records, n_headers), one per partition."""
+    of (blob, batch_off, n_records, n_headers), one per partition (of the
+    partitions in `only`, when given)."""
     kinds = [
         (C1_SHAPE, 100),
         (C2_SHAPE, 1000),
@@ -224,7 +225,7 @@ def mixed_partitions(n_partitions: int, batches_each: int, seed: int = SEED_BASE
         (Shape(key_len=4, val_len=6, n_headers=0), 1),   # control-batch sized record
     ]
     out = []
-    for p in range(n_partitions):
+    for p in (range(n_partitions) if only is None else only):
         shape, r = kinds[p % 5]
         out.append(make_batches(shape, np.full(batches_each, r), seed + 1000 * p))
     return out
