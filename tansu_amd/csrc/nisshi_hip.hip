@@ -428,76 +428,113 @@ constexpr int kWalkGlobal = 2;  // records the streamed walk cannot express: wal
 
 // ---- the walk from global memory
 //
-// One wave per batch.  Record starts are found up to 64 at a time by
-// speculation: lane i assumes that the i-th next record starts i * S bytes on, S
-// being the size of the record before, and decodes the length varint there.
-// Lanes up to and including the first one whose size differs from S did start on
-// a record, and the walk resumes after that lane's record.  Each resolved record
-// is then decoded by its lane and must end where its length said.  This is the
-// walk for batches the streamed walk leaves: records too large for its ring, or
-// of a shape it cannot express.  Starts at record k0, byte pos0 of the record data.
+// One workgroup of kWalkWaves waves per batch.  Record starts are found up to
+// 64 * kWalkWaves at a time by speculation: thread i assumes that the i-th next
+// record starts i * S bytes on, S being the size of the record before, and
+// decodes the length varint there.  Threads up to and including the first one
+// whose size differs from S did start on a record, and the walk resumes after
+// that thread's record: a wave's records count only when every wave before it
+// found all 64 of its guesses right, which the waves tell each other through LDS.
+// Each resolved record is then decoded by its thread and must end where its
+// length said.  This is the walk for batches the streamed walk leaves: large
+// batches, records too large for its ring, or of a shape it cannot express.
+// Starts at record k0, byte pos0 of the record data.  Every thread of the
+// workgroup calls it, with the same arguments; all return the same value.
+constexpr int kWalkWaves = 4;
+
+struct WalkShare {            // one wave's word to the others, two rounds' worth
+    uint32_t taken[2];        // records of the wave that count if the waves before it were full
+    uint32_t full[2];         // all 64 guesses were records of size S
+    uint32_t next_pos[2];     // where the walk goes on after the wave's last record
+    uint32_t next_size[2];    // and that record's size
+    uint32_t bad[2];          // the first guess of the round is no record
+    // found while the records are decoded, read only after the round's second meeting point
+    uint32_t wrong[2];        // a record did not decode, or did not end where its length said
+    uint32_t full_cap[2];     // the header columns are full
+};
+
 __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
-                                           HeaderRuns &runs, uint32_t k0, uint32_t pos0, int lane) {
+                                           HeaderRuns &runs, uint32_t &first_rec, uint32_t k0, uint32_t pos0,
+                                           int lane, int wave, WalkShare *share) {
     uint32_t count = uni(c.record_count[b]);
     uint64_t rbase = uni(c.rec_base[b]);
     Reader rd(blob + uni64(c.data_off[b]), uni(c.data_len[b]));
     uint32_t pos = pos0;
     uint32_t S = count > k0 ? (rd.len - pos0) / (count - k0) : 0;
-    for (uint32_t k = k0; k < count;) {
-        uint32_t m = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
-        uint32_t found = 0, my_start = 0, my_size = 0, my_used = 0;
-        int32_t my_len = 0;
+    uint32_t tid = (uint32_t)wave * kWave + (uint32_t)lane;
+    constexpr uint32_t kWide = kWave * kWalkWaves;
+    int outcome = kWalkDone;
+    uint32_t round = 0;
+    for (uint32_t k = k0; k < count && outcome == kWalkDone; round++) {
+        uint32_t par = round & 1;
+        uint32_t m = count - k < kWide ? count - k : kWide;
         // Touch where the round after this one will look, so that its lines are on
-        // their way from HBM while this round is parsed (the rounds of one wave run
-        // one after the other, each would otherwise start with a cold miss).
+        // their way from HBM while this round is parsed.
         uint32_t touched = 0;
         {
-            uint64_t ahead = (uint64_t)pos + (uint64_t)(m + (uint32_t)lane) * S;
+            uint64_t ahead = (uint64_t)pos + (uint64_t)(m + tid) * S;
             typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
             if (ahead + 4 <= rd.len)
                 touched = *(gbl_u32 *)((reinterpret_cast<uintptr_t>(rd.data) + ahead) & ~uintptr_t(3));
         }
-        while (found < m) {
-            uint32_t lanes = m - found;
-            uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
-            bool in = (uint32_t)lane < lanes && guess64 < rd.len;
-            uint32_t guess = in ? (uint32_t)guess64 : 0;
-            int32_t len = 0;
-            uint32_t used = 0;
-            bool ok = in && fast_varint(rd.get64(guess), used, len);
-            // the whole record lies inside the data (this also catches a varint cut short)
-            ok = ok && len >= 0 && (uint64_t)guess + used + (uint32_t)len <= rd.len;
-            uint32_t size = ok ? used + (uint32_t)len : 0;
-            uint64_t okmask = __ballot(ok);
-            if (!(okmask & 1)) return kWalkExact;
-            uint64_t same = __ballot(ok && size == S);
-            uint32_t good = ~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64;
-            uint32_t v = good;  // lanes below `good` are records of size S
-            if (good < 64 && ((okmask >> good) & 1)) v = good + 1;
-            if (v > lanes) v = lanes;
-            v = uni(v);
-            int src = (lane - (int)found) & 63;
-            uint32_t s_start = __shfl(guess, src, 64);
-            uint32_t s_size = __shfl(size, src, 64);
-            uint32_t s_used = __shfl(used, src, 64);
-            int32_t s_len = __shfl(len, src, 64);
-            if ((uint32_t)lane >= found && (uint32_t)lane < found + v) {
-                my_start = s_start;
-                my_size = s_size;
-                my_used = s_used;
-                my_len = s_len;
-            }
-            S = (uint32_t)__builtin_amdgcn_readlane((int)size, (int)v - 1);
-            pos = (uint32_t)__builtin_amdgcn_readlane((int)guess, (int)v - 1) + S;
-            found += v;
+        // ---- where the records start
+        uint64_t guess64 = (uint64_t)pos + (uint64_t)tid * S;
+        bool in = tid < m && guess64 < rd.len;
+        uint32_t guess = in ? (uint32_t)guess64 : 0;
+        int32_t len = 0;
+        uint32_t used = 0;
+        bool ok = in && fast_varint(rd.get64(guess), used, len);
+        // the whole record lies inside the data (this also catches a varint cut short)
+        ok = ok && len >= 0 && (uint64_t)guess + used + (uint32_t)len <= rd.len;
+        uint32_t size = ok ? used + (uint32_t)len : 0;
+        uint64_t okmask = __ballot(ok);
+        uint64_t same = __ballot(ok && size == S);
+        uint32_t good = ~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64;
+        uint32_t v = good;  // lanes below `good` are records of size S
+        if (good < 64 && ((okmask >> good) & 1)) v = good + 1;
+        uint32_t mine = m > (uint32_t)wave * kWave ? m - (uint32_t)wave * kWave : 0;  // the wave's share of m
+        if (mine > (uint32_t)kWave) mine = kWave;
+        if (v > mine) v = mine;
+        v = uni(v);
+        if (lane == 0) {
+            share[wave].taken[par] = v;
+            share[wave].full[par] = same == ~0ull ? 1 : 0;
+            share[wave].next_size[par] = v ? (uint32_t)__builtin_amdgcn_readlane((int)size, (int)(v ? v - 1 : 0)) : 0;
+            share[wave].next_pos[par] = v ? (uint32_t)__builtin_amdgcn_readlane((int)guess, (int)(v ? v - 1 : 0)) +
+                                                (uint32_t)__builtin_amdgcn_readlane((int)size, (int)(v ? v - 1 : 0))
+                                          : 0;
+            share[wave].bad[par] = wave == 0 && !(okmask & 1) ? 1 : 0;
+            share[wave].wrong[par] = 0;
+            share[wave].full_cap[par] = 0;
         }
-        // ---- one lane per record: the fields after the length
-        bool live = (uint32_t)lane < m;
-        uint32_t end = my_start + my_size;
-        uint32_t p = my_start + my_used;
-        bool ok = live;
+        __syncthreads();
+        // ---- which waves' records count: all up to the first that is not full
+        uint32_t taken_before = 0, n_taken = 0, my_taken = 0;
+        bool open = true;
+        uint32_t new_pos = pos, new_S = S;
+#pragma unroll
+        for (int q = 0; q < kWalkWaves; q++) {
+            uint32_t tq = share[q].taken[par];
+            bool counts = open && tq > 0;
+            if (q == wave) my_taken = counts ? tq : 0, taken_before = n_taken;
+            if (counts) {
+                n_taken += tq;
+                new_pos = share[q].next_pos[par];
+                new_S = share[q].next_size[par];
+            }
+            open = open && share[q].full[par] && tq == (uint32_t)kWave;
+        }
+        if (share[0].bad[par]) {
+            outcome = kWalkExact;  // the same in every wave
+            break;
+        }
+        // ---- one thread per record: the fields after the length
+        bool live = (uint32_t)lane < my_taken;
+        uint32_t end = guess + size;
+        uint32_t p = guess + used;
+        ok = live;
         RecordFields f;
-        f.length = my_len;
+        f.length = len;
         f.attributes = 0;
         f.timestamp_delta = 0;
         f.offset_delta = 0;
@@ -505,66 +542,92 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
         f.key_len = f.val_len = -1;
         f.hdr_count = 0;
         if (live) {
-            uint32_t used;
+            uint32_t n;
             uint64_t w0 = rd.get64(p);  // attributes, then the timestamp delta
             f.attributes = (uint32_t)w0 & 0xffu;
-            if (fast_varlong((uint32_t)(w0 >> 8), used, f.timestamp_delta)) {
-                p += 1 + used;
+            if (fast_varlong((uint32_t)(w0 >> 8), n, f.timestamp_delta)) {
+                p += 1 + n;
             } else {
                 p += 1;
                 ok = rd.varlong(p, f.timestamp_delta) == NISSHI_OK;
             }
-            ok = fast_varint(rd.get64(p), used, f.offset_delta) && ok;
-            p += used;
-            ok = fast_varint(rd.get64(p), used, f.key_len) && ok;
-            p += used;
+            ok = fast_varint(rd.get64(p), n, f.offset_delta) && ok;
+            p += n;
+            ok = fast_varint(rd.get64(p), n, f.key_len) && ok;
+            p += n;
             f.key_off = p;
             ok = ok && f.key_len >= -1 && p <= end && (uint32_t)(f.key_len < 0 ? 0 : f.key_len) <= end - p;
             p += ok && f.key_len > 0 ? (uint32_t)f.key_len : 0u;
-            ok = fast_varint(rd.get64(p), used, f.val_len) && ok;
-            p += used;
+            ok = fast_varint(rd.get64(p), n, f.val_len) && ok;
+            p += n;
             f.val_off = p;
             ok = ok && f.val_len >= -1 && p <= end && (uint32_t)(f.val_len < 0 ? 0 : f.val_len) <= end - p;
             p += ok && f.val_len > 0 ? (uint32_t)f.val_len : 0u;
-            ok = fast_varint(rd.get64(p), used, f.hdr_count) && ok;
-            p += used;
+            ok = fast_varint(rd.get64(p), n, f.hdr_count) && ok;
+            p += n;
             // a header is at least two bytes: a count the record cannot hold is an error
             ok = ok && f.hdr_count >= 0 && p <= end && (uint32_t)f.hdr_count <= (end - p) / 2;
         }
         uint32_t hc = ok ? (uint32_t)f.hdr_count : 0;
         uint32_t slot = 0;
+        bool no_room = false;
         if (__any(hc != 0)) {
             uint32_t piece;
             bool one_piece;
-            if (!runs.take(hc, m, count - k - m, lane, slot, piece, one_piece)) {
-                if (lane == 0) c.status[b] = NISSHI_CAPACITY;
-                return kWalkDone;
-            }
-            for (uint32_t j = 0; j < hc && ok; j++) {
-                uint32_t used, ko, vo;
-                int32_t kl, vl;
-                ok = fast_varint(rd.get64(p), used, kl);
-                p += used;
-                ko = p;
-                ok = ok && kl >= -1 && p <= end && (uint32_t)(kl < 0 ? 0 : kl) <= end - p;
-                p += ok && kl > 0 ? (uint32_t)kl : 0u;
-                ok = fast_varint(rd.get64(p), used, vl) && ok;
-                p += used;
-                vo = p;
-                ok = ok && vl >= -1 && p <= end && (uint32_t)(vl < 0 ? 0 : vl) <= end - p;
-                p += ok && vl > 0 ? (uint32_t)vl : 0u;
-                if (ok) {
-                    store_header(c, slot + j, ko, kl, vo, vl);
+            uint32_t had = runs.total;
+            uint32_t left = count - k - taken_before - my_taken;
+            if (!runs.take(hc, my_taken, left, lane, slot, piece, one_piece)) {
+                no_room = true;
+            } else {
+                if (had == 0) first_rec = k + taken_before + (uint32_t)__ffsll((long long)__ballot(hc != 0)) - 1;
+                for (uint32_t j = 0; j < hc && ok; j++) {
+                    uint32_t n, ko, vo;
+                    int32_t kl, vl;
+                    ok = fast_varint(rd.get64(p), n, kl);
+                    p += n;
+                    ko = p;
+                    ok = ok && kl >= -1 && p <= end && (uint32_t)(kl < 0 ? 0 : kl) <= end - p;
+                    p += ok && kl > 0 ? (uint32_t)kl : 0u;
+                    ok = fast_varint(rd.get64(p), n, vl) && ok;
+                    p += n;
+                    vo = p;
+                    ok = ok && vl >= -1 && p <= end && (uint32_t)(vl < 0 ? 0 : vl) <= end - p;
+                    p += ok && vl > 0 ? (uint32_t)vl : 0u;
+                    if (ok) {
+                        store_header(c, slot + j, ko, kl, vo, vl);
+                    }
                 }
             }
         }
         // the fields must end exactly where the length said
-        if (__any(live && (!ok || p != end))) return kWalkExact;
-        if (live) store_record(c, rbase + k, (uint32_t)lane, f, slot);
-        k += m;
+        bool wrong = __any(live && !no_room && (!ok || p != end));
+        if (live && !no_room && !wrong) store_record(c, rbase + k + taken_before, (uint32_t)lane, f, slot);
+        // what went wrong in any wave ends the walk in all of them: told at the next
+        // round's meeting point, or at the one after the loop
+        if (lane == 0) {
+            if (wrong) share[wave].wrong[par] = 1;
+            if (no_room) share[wave].full_cap[par] = 1;
+        }
+        __syncthreads();
+        uint32_t any_bad = 0, any_full = 0;
+#pragma unroll
+        for (int q = 0; q < kWalkWaves; q++) {
+            any_bad |= share[q].wrong[par];
+            any_full |= share[q].full_cap[par];
+        }
+        if (any_full) {
+            if (tid == 0) c.status[b] = NISSHI_CAPACITY;
+            outcome = kWalkDone;
+            asm volatile("" ::"v"(touched));
+            break;
+        }
+        if (any_bad) outcome = kWalkExact;
+        k += n_taken;
+        pos = new_pos;
+        S = new_S;
         asm volatile("" ::"v"(touched));  // the touch is waited for here, a round after it was issued
     }
-    return kWalkDone;
+    return outcome;
 }
 
 // ---- the streamed walk
@@ -1050,43 +1113,60 @@ __device__ __forceinline__ void exact_walk(const uint8_t *blob, uint32_t b, cons
 // from global memory; flagged batches from where the streamed walk stopped; the
 // sequential walk for batches that need the reference's exact outcome; and the
 // batch's share of the totals, its status being final here.
-__global__ __launch_bounds__(64) void slow_walk_kernel(const uint8_t *blob, const uint64_t *batch_off,
-                                                       uint32_t n, nisshi_columns c, Work w,
-                                                       uint64_t rec_cap, uint64_t hdr_cap,
-                                                       const CrcTables *t) {
+__global__ __launch_bounds__(kWave * kWalkWaves) void slow_walk_kernel(const uint8_t *blob, const uint64_t *batch_off,
+                                                                       uint32_t n, nisshi_columns c, Work w,
+                                                                       uint64_t rec_cap, uint64_t hdr_cap,
+                                                                       const CrcTables *t) {
+    __shared__ WalkShare share[kWalkWaves];
+    __shared__ uint32_t hdr_total[kWalkWaves], hdr_first_rec[kWalkWaves], hdr_first_slot[kWalkWaves];
     uint32_t b = blockIdx.x;
-    int lane = threadIdx.x;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool lead = threadIdx.x == 0;
     if (b >= n) return;
     uint32_t flags = uni(w.flags[b]);
     uint32_t chunks = uni(w.n_chunks[b]);
     bool big = chunks >= kBigChunks;
     // the usual batch was done by the streamed walk: nothing left
     if (!big && flags == 0 && uni(c.status[b]) == NISSHI_OK) return;
-    if (big && lane == 0) c.crc_computed[b] = crc_combine(batch_off, c.batch_length, b, chunks, w, t);
+    if (big && lead) c.crc_computed[b] = crc_combine(batch_off, c.batch_length, b, chunks, w, t);
     bool ok = uni(c.status[b]) == NISSHI_OK;
     if (ok && !(flags & kFlagExact) && (big || (flags & kFlagGlobal))) {
         HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
-        uint32_t k = 0, pos = 0;
+        uint32_t k = 0, pos = 0, before = 0, before_slot = 0;
         bool fits = true;
         if (flags & kFlagGlobal) {
             k = uni(w.resume_k[b]);
             pos = uni(w.resume_pos[b]);
-            runs.total = uni(c.hdr_count[b]);
-            runs.first_slot = uni(c.hdr_base[b]);
+            before = uni(c.hdr_count[b]);  // the streamed walk's headers come first
+            before_slot = uni(c.hdr_base[b]);
         } else if ((uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
-            if (lane == 0) c.status[b] = NISSHI_CAPACITY;
             fits = false;
         }
-        if (fits) {
-            int st = walk_global(blob, b, c, runs, k, pos, lane);
+        if (!fits) {
+            if (lead) c.status[b] = NISSHI_CAPACITY;
+        } else {
+            uint32_t first_rec = 0xffffffffu;
+            int st = walk_global(blob, b, c, runs, first_rec, k, pos, lane, wave, share);
+            // the batch's headers: every wave took runs of its own
             if (lane == 0) {
-                c.hdr_count[b] = runs.total;
-                c.hdr_base[b] = runs.first_slot;
+                hdr_total[wave] = runs.total;
+                hdr_first_rec[wave] = runs.total ? first_rec : 0xffffffffu;
+                hdr_first_slot[wave] = runs.first_slot;
+            }
+            __syncthreads();
+            if (lead) {
+                uint32_t total = before, first = 0xffffffffu, slot = before_slot;
+                for (int q = 0; q < kWalkWaves; q++) {
+                    total += hdr_total[q];
+                    if (!before && hdr_first_rec[q] < first) first = hdr_first_rec[q], slot = hdr_first_slot[q];
+                }
+                c.hdr_count[b] = total;
+                c.hdr_base[b] = slot;
             }
             if (st != kWalkDone) flags |= kFlagExact;
         }
     }
-    if (lane == 0) {
+    if (lead) {
         if (ok && (flags & kFlagExact) && c.status[b] == NISSHI_OK) exact_walk(blob, b, c, w, rec_cap, hdr_cap);
         if (c.status[b] != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
         if (flags & kFlagExact) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
