@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -166,10 +167,14 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint3
 constexpr int kScanItems = 8;
 
 __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_columns c, Work w,
-                                                            uint32_t min_chunks) {
+                                                            uint32_t min_chunks, const uint64_t *before) {
     __shared__ uint64_t wave_sum[16];
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint64_t run = 0;  // records in the low half, work items in the high half
+    // records in the low half, work items in the high half.  A call may decode one
+    // slice of a blob: its record and header slots then go on where the slice
+    // before it ended, whose totals are `before`.
+    uint64_t run = before ? (uint32_t)before[0] : 0;
+    if (threadIdx.x == 0) w.totals[1] = before ? before[1] : 0;
     for (uint32_t base = 0; base < n; base += blockDim.x * kScanItems) {
         uint32_t b0 = base + threadIdx.x * kScanItems;
         uint64_t v[kScanItems], mine = 0;
