@@ -725,7 +725,8 @@ inline Result<std::vector<Compaction>> compact(Codec &codec, const std::vector<r
         blob.insert(blob.end(), e.data(), e.data() + e.len());
         off[b + 1] = blob.size();
     }
-    std::vector<uint8_t> out(blob.size() + 64);
+    // a rebuilt length may take up to four bytes more than the stored one, on records of seven and more
+    std::vector<uint8_t> out(blob.size() + blob.size() / 7 * 4 + 64);
     std::vector<uint64_t> out_off(n + 1, 0);
     std::vector<uint32_t> removed(n + 1, 0);
     std::vector<int32_t> action(n + 1, 0), status(n + 1, 0);

@@ -417,7 +417,8 @@ class Codec:
         off = np.ascontiguousarray(batch_off, dtype=np.uint64)
         n_b = len(off) - 1
         grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
-        out_cap = len(arr) + 64 if out_cap is None else out_cap
+        # a rebuilt length may take up to four bytes more than the stored one, on records of seven and more
+        out_cap = len(arr) + len(arr) // 7 * 4 + 64 if out_cap is None else out_cap
         out = np.zeros(max(out_cap, 1), dtype=np.uint8)
         out_off = np.zeros(n_b + 1, dtype=np.uint64)
         removed = np.zeros(max(n_b, 1), dtype=np.uint32)

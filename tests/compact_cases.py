@@ -4,6 +4,7 @@ storage.rs:283-312), independent of the C restatement."""
 import numpy as np
 
 from tansu_amd import columns as C
+import oracle
 from util import body_size, build_batch
 
 
@@ -31,6 +32,16 @@ def make_partition(n_batches, per_batch, n_keys, seed=0, keyless=0.1, control_ev
         hdr = dict(base_offset=base, last_offset_delta=n - 1, attributes=attributes,
                    base_timestamp=1_700_000_000_000 + b, max_timestamp=1_700_000_000_000 + b + n)
         batch = build_batch(hdr, recs)
+        if stored_length_off:
+            # the same records with a stored length of 0: Record::decode never uses it
+            # (record.rs:259-265), and a rebuilt batch carries the body sizes instead
+            full = dict(magic=2, partition_leader_epoch=-1, producer_id=-1)
+            full.update(hdr)
+            cols, payload, src_off = C.columns_from_records([(full, [C.Record(0, r.attributes, r.timestamp_delta,
+                                                                              r.offset_delta, r.key, r.value, r.headers)
+                                                                     for r in recs])])
+            st, batch, _ = oracle.encode_columns(cols, 1, payload, src_off)
+            assert st == C.OK
         out.append(batch)
         base += n
     return out
@@ -78,4 +89,5 @@ CASES = {
     "headers_and_long_keys": dict(n_batches=7, per_batch=50, n_keys=20, headers=True, long_keys=True),
     "one_key": dict(n_batches=8, per_batch=25, n_keys=1, keyless=0.0),
     "single_batch": dict(n_batches=1, per_batch=300, n_keys=40),
+    "stored_lengths_differ": dict(n_batches=4, per_batch=80, n_keys=6, stored_length_off=True),
 }

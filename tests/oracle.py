@@ -259,7 +259,8 @@ def compact_partition(batches):
     n = len(bufs)
     ptrs = (ctypes.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
     lens = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in bufs])
-    cap = sum(len(b) for b in bufs) + 64
+    total = sum(len(b) for b in bufs)
+    cap = total + total // 7 * 4 + 64            # a rebuilt length may be up to four bytes longer
     out = np.zeros(cap, dtype=np.uint8)
     out_off = np.zeros(n + 1, dtype=np.uint64)
     removed = np.zeros(max(n, 1), dtype=np.int64)
