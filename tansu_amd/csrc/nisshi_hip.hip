@@ -51,6 +51,8 @@ struct Work {
 __global__ void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
                                     int by_value, nisshi_columns c, Work w) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    // the call's totals start at zero: their first users are the kernels after this one
+    if (b < 8) w.totals[b] = 0;
     if (b >= n) return;
     const uint8_t *p = blob + batch_off[b];
     uint64_t len = batch_off[b + 1] - batch_off[b];
@@ -246,15 +248,13 @@ __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_c
 
 // ------------------------------------------------------------ CRC-32C
 
-// One wave per work item, as many passes as the grid needs: item -> (batch, chunk)
+// The CRC work items first, first + stride, ..., one wave each: item -> (batch, chunk)
 // by binary search in the scan.
-__global__ void crc_chunks_kernel(const uint8_t *blob, const uint64_t *batch_off,
-                                  const int32_t *batch_length, uint32_t n, uint32_t *crc_out,
-                                  Work w, const CrcTables *t) {
-    int lane = threadIdx.x & 63;
+__device__ __forceinline__ void crc_chunk_items(uint32_t first, uint32_t stride, const uint8_t *blob,
+                                                const uint64_t *batch_off, const int32_t *batch_length, uint32_t n,
+                                                uint32_t *crc_out, const Work &w, const CrcTables *t, int lane) {
     uint32_t total = w.chunk_base[n];
-    for (uint32_t item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); item < total;
-         item += gridDim.x * kWavesPerBlock) {
+    for (uint32_t item = first; item < total; item += stride) {
         uint32_t lo_b = 0, hi_b = n;  // largest b with chunk_base[b] <= item and work items of its own
         while (hi_b - lo_b > 1) {
             uint32_t mid = (lo_b + hi_b) >> 1;
@@ -282,6 +282,14 @@ __global__ void crc_chunks_kernel(const uint8_t *blob, const uint64_t *batch_off
             if (chunks == 1) crc_out[b] = hi == lo ? 0u : ~r;
         }
     }
+}
+
+// One wave per work item, as many passes as the grid needs.
+__global__ void crc_chunks_kernel(const uint8_t *blob, const uint64_t *batch_off,
+                                  const int32_t *batch_length, uint32_t n, uint32_t *crc_out,
+                                  Work w, const CrcTables *t) {
+    crc_chunk_items(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), gridDim.x * kWavesPerBlock, blob, batch_off,
+                    batch_length, n, crc_out, w, t, threadIdx.x & 63);
 }
 
 // The CRC of a batch of more than one chunk from its chunks' residues:
@@ -1023,11 +1031,19 @@ template <int kRows, int kWaves>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
-                                                          uint64_t hdr_cap, const CrcTables *t) {
+                                                          uint64_t hdr_cap, const CrcTables *t,
+                                                          uint32_t chunk_groups) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
     __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
-    uint32_t b = blockIdx.x;
     int lane = threadIdx.x;
+    // The first chunk_groups workgroups take the CRC work items of the batches of
+    // kBigChunks chunks and more (none, most of the time): in this grid rather than
+    // in a launch of their own, and ahead of the batches so that they start first.
+    if (blockIdx.x < chunk_groups) {
+        crc_chunk_items(blockIdx.x, chunk_groups, blob, batch_off, c.batch_length, n, c.crc_computed, w, t, lane);
+        return;
+    }
+    uint32_t b = blockIdx.x - chunk_groups;
     if (b >= n) return;
     uint32_t chunks = uni(w.n_chunks[b]);
     if (chunks == 0 || chunks >= kBigChunks) return;
