@@ -163,13 +163,15 @@ int nisshi_hip_count_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t bl
  * Header slots are handed out in runs from one cursor while batches decode in
  * parallel: a record's headers are contiguous from hdr_base, but the order of
  * runs between batches is not defined and a batch may leave up to 4096 slots of
- * its last run unused, so size hdr_cap with that slack (a batch whose headers
- * do not fit gets NISSHI_CAPACITY).  Batches whose records all carry the same
- * number of headers use exactly their header count.  A batch that ends on the
- * sequential walk (totals.n_exact: a record whose length disagrees with its
- * fields, or one that does not decode) starts over with fresh slots and leaves
- * those of its first attempt unused; headers + 4096 slots more a batch, or
- * blob_len / 2 + 4096 * n_batches in all, cover that too. */
+ * its last run unused (four times that for a batch of 448 KiB and more, or one
+ * whose records the streamed walk cannot express: four waves walk it, each with
+ * runs of its own), so size hdr_cap with that slack (a batch whose headers do not
+ * fit gets NISSHI_CAPACITY).  Batches whose records all carry the same number of
+ * headers use exactly their header count.  A batch that ends on the sequential
+ * walk (totals.n_exact: a record whose length disagrees with its fields, or one
+ * that does not decode) starts over with fresh slots and leaves those of its
+ * first attempt unused; blob_len + 4096 * n_batches slots in all cover every
+ * case (a header is at least two bytes). */
 int nisshi_hip_decode_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
                           const uint64_t *d_batch_off, uint32_t n_batches, int by_value,
                           const nisshi_columns *d_cols, uint64_t rec_cap, uint64_t hdr_cap,

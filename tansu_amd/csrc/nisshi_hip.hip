@@ -588,7 +588,8 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
             uint32_t piece;
             bool one_piece;
             uint32_t had = runs.total;
-            uint32_t left = count - k - taken_before - my_taken;
+            // what the wave may still have to store in this walk: its share of the records to come
+            uint32_t left = (count - k - taken_before - my_taken) / kWalkWaves;
             if (!runs.take(hc, my_taken, left, lane, slot, piece, one_piece)) {
                 no_room = true;
             } else {
