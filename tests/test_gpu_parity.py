@@ -356,6 +356,50 @@ def test_full_size_properties(codec, name):
     assert bool((out[:len(blob)] == d_blob[:len(blob)]).all())
 
 
+@pytest.mark.parametrize("name", ["c5", "c4"])
+def test_full_size_ragged_and_mixed(codec, name):
+    """The ragged workload at its full size (batches of up to 10 000 records: the
+    walks of large batches at scale) and a GPU's share of the mixed one: totals,
+    CRCs, per-record arithmetic (offset and timestamp deltas count up from 0 in
+    every batch), the largest batch in full against the oracle, and the re-encode
+    reproducing the input byte for byte."""
+    import torch
+    from tansu_amd import shard
+    if name == "c5":
+        shape, counts, seed = synth.config("c5", 1.0)
+        blob, off, nr, nh = synth.make_batches(shape, counts, seed)
+    else:
+        _, blob, off, nr, nh, _ = shard.make_shard("c4", 0.25, 0, 1)
+    n_b = len(off) - 1
+    crc_patch(codec, blob, off)
+    cols, totals, d_blob, d_off = gpu_decode(codec, blob, off, rec_cap=nr, hdr_cap=max(nh, 1) + 4096 * 16)
+    assert (totals.n_records, totals.n_failed, totals.n_exact) == (nr, 0, 0)
+    t = cols.t
+    assert int(t["hdr_count"][:n_b].sum()) == nh
+    assert bool((t["status"][:n_b] == 0).all()) and bool((t["crc"][:n_b] == t["crc_computed"][:n_b]).all())
+    assert int(t["record_count"][:n_b].sum()) == nr
+    # record r of a batch has offset_delta = timestamp_delta = its index in the batch
+    base = t["rec_base"][:n_b].to(torch.int64)
+    count = t["record_count"][:n_b].to(torch.int64)
+    assert bool((base == torch.cumsum(count, 0) - count).all())
+    index = torch.arange(nr, device=base.device) - torch.repeat_interleave(base, count)
+    f = cols.field
+    assert bool((f("offset_delta")[:nr] == index).all())
+    assert bool((f("timestamp_delta")[:nr] == index).all())
+    b = int(torch.argmax(count))
+    sub = blob[int(off[b]):int(off[b + 1])]
+    st, c, _, _ = oracle.decode_columns(sub, np.array([0, len(sub)], dtype=np.uint64))
+    assert st == 0
+    g0, r = int(base[b]), int(count[b])
+    for name_ in ("length", "key_off", "key_len", "val_off", "val_len", "timestamp_delta", "rhdr_count"):
+        assert (f(name_)[g0:g0 + r].cpu().numpy() == c[name_][:r]).all(), name_
+    out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
+    te = codec.encode_dev(cols, n_b, d_blob, t["data_off"], out, len(blob), out_off)
+    assert te.out_bytes == len(blob)
+    assert bool((out[:len(blob)] == d_blob[:len(blob)]).all())
+
+
 def test_host_api_with_pinned_buffers(codec):
     """The host-buffer entry point reading a page-locked blob and writing page-locked
     columns gives what it gives with ordinary memory: the oracle's columns."""

@@ -49,3 +49,18 @@ def test_ragged_and_determinism():
     st, cols, n_rec, _ = oracle.decode_columns(blob, off)
     assert (cols["status"] == C.OK).all() and n_rec == nr == int(counts.sum())
     assert list(cols["record_count"]) == list(counts)
+
+
+def test_mixed_shard_is_a_gpus_share():
+    """The mixed workload of one rank: its partitions laid out as one blob whose
+    batches the CPU restatement accepts, five shapes in turn, 64 batches each."""
+    from tansu_amd import shard
+    _, blob, off, nr, nh, nb = shard.make_shard("c4", 10 / 128, 1, 2)
+    assert nb == 10 * 64 and len(off) == nb + 1 and int(off[-1]) == len(blob)
+    assert (np.diff(off.astype(np.int64)) > 61).all()
+    st, cols, got_r, got_h = oracle.decode_columns(blob, off)
+    assert st == 0 and (cols["status"] == 0).all() and (got_r, got_h) == (nr, nh)
+    # rank 1 of 8 devices holds partitions 1, 9, 17, ...: shapes (p mod 5) 1, 4, 2, 0, 3, ...
+    per_batch = cols["record_count"].reshape(10, 64)
+    assert (per_batch == per_batch[:, :1]).all()
+    assert per_batch[:, 0].tolist()[:5] == [1000, 1, 4, 100, 1]
