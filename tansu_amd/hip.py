@@ -93,6 +93,13 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -m tansu_amd.build` "
                           "(there is no CPU fallback for the HIP codec)")
+    # PyTorch ships a HIP runtime of its own; loading it first lets this library
+    # bind to the same copy, whatever the order the caller imports things in (two
+    # runtimes in one process do not share a device context)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
     lib.nisshi_hip_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
