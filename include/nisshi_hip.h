@@ -189,7 +189,11 @@ int nisshi_hip_encode_dev(nisshi_hip_ctx *ctx, const nisshi_columns *d_cols, uin
 
 /* Host-buffer forms: copy the blob to the device, decode, copy the columns
  * back.  The library owns the device buffers.  cols holds host pointers sized
- * rec_cap / hdr_cap. */
+ * rec_cap / hdr_cap.  A large blob is decoded in slices of whole batches (64 MiB,
+ * or NISSHI_SLICE_BYTES in the environment when the context is created; 16 at
+ * most) so that the copies of one slice overlap the kernels of another; the
+ * result is that of one call, except that header slots left unused at the end of
+ * a slice stay unused.  The overlap needs page-locked buffers (below). */
 int nisshi_hip_decode(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
                       const uint64_t *batch_off, uint32_t n_batches, int by_value,
                       const nisshi_columns *cols, uint64_t rec_cap, uint64_t hdr_cap,
