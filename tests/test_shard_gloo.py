@@ -61,3 +61,17 @@ def test_two_ranks_shard_and_time_together():
 def test_shard_seeds_differ():
     from tansu_amd import shard
     assert len({shard.shard_seed(1, r) for r in range(8)}) == 8
+
+
+def test_mixed_workload_ranks_hold_their_own_partitions():
+    """The mixed workload: partition p lives on device p mod 8, so the ranks of a
+    job hold different partitions of the same five shapes, the same work each."""
+    from tansu_amd import shard
+    a = shard.make_shard("c4", 10 / 128, 0, 2)
+    b = shard.make_shard("c4", 10 / 128, 1, 2)
+    assert a[5] == b[5] == 640
+    assert bytes(a[1][:4096]) != bytes(b[1][:4096])
+    # rank 0 holds partitions 0, 8, 16, ...: shapes (p mod 5) 0, 3, 1, 4, 2, ...; rank 1: 1, 4, 2, 0, 3, ...
+    sizes_a = np.diff(a[2].astype(np.int64)).reshape(10, 64)[:, 0]
+    sizes_b = np.diff(b[2].astype(np.int64)).reshape(10, 64)[:, 0]
+    assert sorted(sizes_a[:5]) == sorted(sizes_b[:5]) and list(sizes_a[:5]) != list(sizes_b[:5])
