@@ -1130,6 +1130,38 @@ __device__ __forceinline__ void exact_walk(const uint8_t *blob, uint32_t b, cons
     c.hdr_base[b] = first_slot;
 }
 
+// Batches of a few hundred bytes, a lane each: a workgroup a batch spends more on
+// starting than on the batch (a producer that does not linger sends one record a
+// batch).  The CRC bit by bit, the records by the sequential walk (exact_walk:
+// Record::decode in order, the reference's outcomes by construction).  The batch
+// is then taken off the other kernels' hands (no CRC work item, no flag).
+constexpr uint32_t kTinyBytes = 1024;
+
+__global__ __launch_bounds__(256) void tiny_batch_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
+                                                         nisshi_columns c, Work w, uint64_t rec_cap,
+                                                         uint64_t hdr_cap) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    uint64_t at = batch_off[b];
+    if (batch_off[b + 1] - at > kTinyBytes || w.n_chunks[b] == 0) return;  // no CRC item: the header did not get that far
+    const uint8_t *p = blob + at + 21;
+    uint32_t bytes = (uint32_t)c.batch_length[b] - 9;
+    uint32_t r = 0xffffffffu;
+    for (uint32_t i = 0; i < bytes; i++) {
+        r ^= p[i];
+#pragma unroll
+        for (int k = 0; k < 8; k++) r = gf_mulx(r);
+    }
+    c.crc_computed[b] = bytes ? ~r : 0u;
+    w.n_chunks[b] = 0;
+    uint32_t flags = w.flags[b];
+    if (c.status[b] == NISSHI_OK) {
+        exact_walk(blob, b, c, w, rec_cap, hdr_cap);
+        if (flags & kFlagExact) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
+    }
+    w.flags[b] = 0;
+}
+
 // Everything the streamed walk left, one wave per batch: the CRC of batches of
 // kBigChunks chunks or more from their chunks' residues and their record walk
 // from global memory; flagged batches from where the streamed walk stopped; the

@@ -243,6 +243,30 @@ def test_odd_and_malformed_batches(codec):
     assert st[14] == C.OK and st[15] == C.OK            # accepted by the sequential walk
 
 
+def test_small_batches_a_lane_each_and_a_workgroup_each(codec):
+    """A blob whose batches average under 1 KiB is decoded a lane a batch; the same
+    batches beside one large batch (which lifts the average) a workgroup a batch.
+    Both must give the oracle's columns, malformed batches included."""
+    from util import load_vectors, find_batches
+    V = load_vectors()
+    small = odd_batches()
+    for case in V["decode_frames"]:
+        frame = bytes(case["frame"])
+        small += [frame[a:b] for a, b in find_batches(frame)]
+    shape, counts, seed = synth.config("c2", 1 / 8192)
+    big, big_off, _, _ = synth.make_batches(shape, counts, seed)
+    big = bytes(big)
+    assert len(b"".join(small)) / len(small) < 1024 < (len(b"".join(small)) + len(big)) / (len(small) + 1)
+    ga, ca, ta, *_ = check_against_oracle(codec, b"".join(small), offsets_of(small))
+    both = small + [big]
+    gb, cb, tb, *_ = check_against_oracle(codec, b"".join(both), offsets_of(both))
+    n = len(small)
+    for name in ("status", "crc_computed", "record_count", "hdr_count", "attributes", "base_offset"):
+        assert (ga[name][:n] == gb[name][:n]).all(), name
+    # the lane-a-batch path counts as sequential only what had to be (a count the data cannot hold)
+    assert ta.n_exact <= tb.n_exact
+
+
 def test_reencode_of_non_canonical_input(codec):
     # padded varints decode fine and re-encode shorter; the stored length is emitted verbatim
     import torch
