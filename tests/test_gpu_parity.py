@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 from tansu_amd import columns as C, hip, synth
-from util import assert_same, find_batches, load_vectors, offsets_of, record_from_json
+from util import assert_same, build_batch, find_batches, load_vectors, offsets_of, record_from_json
 
 pytestmark = pytest.mark.gpu
 
@@ -441,3 +441,36 @@ def test_host_api_with_pinned_buffers(codec):
     assert st == 0
     from tansu_amd import columns as C
     assert_same(C.unpack(arrays), c, n_b)
+
+
+def test_encode_of_many_small_batches(codec):
+    """From 64 batches on, batches of up to 512 bytes of record data are encoded a
+    lane each: the same bytes as the oracle's, keys, nulls and headers included, in
+    one call with batches that take the wave-a-batch path."""
+    import torch
+    rng = np.random.default_rng(3)
+    batches = []
+    for b in range(150):
+        recs = []
+        for i in range(int(rng.integers(0, 5))):
+            hdrs = [C.Header(b"h%d" % j, None if j % 2 else b"x" * j) for j in range(int(rng.integers(0, 3)))]
+            recs.append(C.Record(0, 0, 7 * i - 3, i, None if i % 3 == 0 else b"k" * int(rng.integers(0, 20)),
+                                 None if i % 4 == 1 else bytes(rng.integers(0, 256, int(rng.integers(0, 90)), dtype=np.uint8)),
+                                 hdrs))
+        batches.append(build_batch(dict(base_offset=b, last_offset_delta=max(len(recs) - 1, 0)), recs))
+    shape, counts, seed = synth.config("c1", 0.001)               # three batches of 11 KB among them
+    big, big_off, _, _ = synth.make_batches(shape, counts, seed)
+    big = bytes(big)
+    batches[50:50] = [big[int(big_off[i]):int(big_off[i + 1])] for i in range(3)]
+    blob, off = b"".join(batches), offsets_of(batches)
+    crc_blob = np.frombuffer(blob, dtype=np.uint8).copy()
+    crc_patch(codec, crc_blob, off)
+    g, c, totals, cols, d_blob, d_off = check_against_oracle(codec, crc_blob, off)
+    n_b = len(batches)
+    out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
+    t = codec.encode_dev(cols, n_b, d_blob, cols.t["data_off"], out, len(blob), out_off)
+    st, want, want_off = oracle.encode_columns(c, n_b, crc_blob, c["data_off"])
+    assert st == C.OK
+    assert out[:t.out_bytes].cpu().numpy().tobytes() == want == crc_blob.tobytes()
+    assert (out_off.cpu().numpy().astype(np.uint64) == want_off).all()
