@@ -181,6 +181,10 @@ def main():
         "kernels_ms": {k: v[0] / v[1] for k, v in sorted(ekt.items(), key=lambda kv: -kv[1][0])},
     }
 
+    # ---- what this device's memory system gives a plain copy (1 GiB read, 1 GiB
+    # written), for reading `frac` against a measured number as well as the nominal peak
+    result["roofline"]["device_copy_gbs"] = device_copy_gbs(dev)
+
     if args.with_copies:
         # the host-buffer entry point: H2D of the blob, the kernels, D2H of the columns;
         # once from ordinary host memory and once from page-locked buffers
@@ -212,6 +216,21 @@ def main():
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def device_copy_gbs(dev, n_bytes=1 << 30, reps=10):
+    """Bytes read plus bytes written per second by a device-to-device copy."""
+    import torch
+    src = torch.empty(n_bytes // 16, 4, dtype=torch.int32, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    t1.record()
+    torch.cuda.synchronize(dev)
+    return 2 * n_bytes * reps / (t0.elapsed_time(t1) * 1e-3) / 1e9
 
 
 def cpu_baseline(blob, off, n_batches, n_records, budget_s=12.0):

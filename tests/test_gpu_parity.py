@@ -444,7 +444,8 @@ def test_host_api_with_pinned_buffers(codec):
 
 
 def test_encode_of_many_small_batches(codec):
-    """From 64 batches on, batches of up to 512 bytes of record data are encoded a
+    """From 64 batches with under 4 KiB of output capacity each on, batches of up to
+    512 bytes of record data are encoded a
     lane each: the same bytes as the oracle's, keys, nulls and headers included, in
     one call with batches that take the wave-a-batch path."""
     import torch
