@@ -1028,23 +1028,28 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
 // wave cannot stream them fast enough) and their records from slow_walk_kernel.
 constexpr uint32_t kBigChunks = 8;
 
-template <int kRows, int kWaves>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
+template <int kRows, int kWaves, int kPack>
+__global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
                                                           uint64_t hdr_cap, const CrcTables *t,
                                                           uint32_t chunk_groups) {
-    __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
-    __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
-    int lane = threadIdx.x;
+    // kPack waves a workgroup, each with a batch, a ring and a shape table of its
+    // own: no wave waits for another (there is no barrier below)
+    __shared__ __attribute__((aligned(16))) uint32_t rings[kPack][RingCfg<kRows>::kRingWords];
+    __shared__ __attribute__((aligned(16))) uint32_t shape_tabs[kPack][kShapeWords];
+    int lane = threadIdx.x & 63;
+    uint32_t wave = uni(threadIdx.x >> 6);
+    uint32_t *ring = rings[wave], *shape_tab = shape_tabs[wave];
     // The first chunk_groups workgroups take the CRC work items of the batches of
     // kBigChunks chunks and more (none, most of the time): in this grid rather than
     // in a launch of their own, and ahead of the batches so that they start first.
     if (blockIdx.x < chunk_groups) {
-        crc_chunk_items(blockIdx.x, chunk_groups, blob, batch_off, c.batch_length, n, c.crc_computed, w, t, lane);
+        crc_chunk_items(blockIdx.x * kPack + wave, chunk_groups * kPack, blob, batch_off, c.batch_length, n,
+                        c.crc_computed, w, t, lane);
         return;
     }
-    uint32_t b = blockIdx.x - chunk_groups;
+    uint32_t b = (blockIdx.x - chunk_groups) * kPack + wave;
     if (b >= n) return;
     uint32_t chunks = uni(w.n_chunks[b]);
     if (chunks == 0 || chunks >= kBigChunks) return;
@@ -1167,16 +1172,18 @@ __global__ __launch_bounds__(256) void tiny_batch_kernel(const uint8_t *blob, co
 // from global memory; flagged batches from where the streamed walk stopped; the
 // sequential walk for batches that need the reference's exact outcome; and the
 // batch's share of the totals, its status being final here.
-__global__ __launch_bounds__(kWave * kWalkWaves) void slow_walk_kernel(const uint8_t *blob, const uint64_t *batch_off,
-                                                                       uint32_t n, nisshi_columns c, Work w,
-                                                                       uint64_t rec_cap, uint64_t hdr_cap,
-                                                                       const CrcTables *t) {
-    __shared__ WalkShare share[kWalkWaves];
-    __shared__ uint32_t hdr_total[kWalkWaves], hdr_first_rec[kWalkWaves], hdr_first_slot[kWalkWaves];
-    uint32_t b = blockIdx.x;
+struct SlowShare {
+    WalkShare walk[kWalkWaves];
+    uint32_t hdr_total[kWalkWaves], hdr_first_rec[kWalkWaves], hdr_first_slot[kWalkWaves];
+};
+
+__device__ __forceinline__ void slow_batch(const uint8_t *blob, const uint64_t *batch_off, uint32_t b,
+                                           const nisshi_columns &c, const Work &w, uint64_t rec_cap, uint64_t hdr_cap,
+                                           const CrcTables *t, SlowShare &sh) {
+    WalkShare *share = sh.walk;
+    uint32_t *hdr_total = sh.hdr_total, *hdr_first_rec = sh.hdr_first_rec, *hdr_first_slot = sh.hdr_first_slot;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool lead = threadIdx.x == 0;
-    if (b >= n) return;
     uint32_t flags = uni(w.flags[b]);
     uint32_t chunks = uni(w.n_chunks[b]);
     bool big = chunks >= kBigChunks;
@@ -1224,6 +1231,30 @@ __global__ __launch_bounds__(kWave * kWalkWaves) void slow_walk_kernel(const uin
         if (ok && (flags & kFlagExact) && c.status[b] == NISSHI_OK) exact_walk(blob, b, c, w, rec_cap, hdr_cap);
         if (c.status[b] != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
         if (flags & kFlagExact) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
+    }
+}
+
+// A workgroup a batch; or, where nearly every batch has nothing left (blobs of
+// small batches), per_group batches in turn after a look at all of them at once.
+template <bool kGrouped>
+__global__ __launch_bounds__(kWave * kWalkWaves) void slow_walk_kernel(const uint8_t *blob, const uint64_t *batch_off,
+                                                                       uint32_t n, nisshi_columns c, Work w,
+                                                                       uint64_t rec_cap, uint64_t hdr_cap,
+                                                                       const CrcTables *t, uint32_t per_group) {
+    __shared__ SlowShare sh;
+    if (!kGrouped) {
+        if (blockIdx.x < n) slow_batch(blob, batch_off, blockIdx.x, c, w, rec_cap, hdr_cap, t, sh);
+        return;
+    }
+    uint64_t mine = (uint64_t)blockIdx.x * per_group + threadIdx.x;  // per_group <= the workgroup's threads
+    bool left = threadIdx.x < per_group && mine < n &&
+                (w.n_chunks[mine] >= kBigChunks || w.flags[mine] != 0 || c.status[mine] != NISSHI_OK);
+    if (!__syncthreads_or(left)) return;
+    for (uint32_t i = 0; i < per_group; i++) {
+        uint64_t b = (uint64_t)blockIdx.x * per_group + i;
+        if (b >= n) return;
+        slow_batch(blob, batch_off, (uint32_t)b, c, w, rec_cap, hdr_cap, t, sh);
+        __syncthreads();  // the next batch reuses the shared state
     }
 }
 
