@@ -42,6 +42,7 @@ struct Work {
     uint32_t *resume_k;     // kFlagGlobal: the first record not yet decoded
     uint32_t *resume_pos;   // and its offset in the record data
     uint64_t *totals;       // [0] record slots [1] header slots [2] failed [3] exact [4] out bytes [5] chunks
+    uint64_t *tile_sum;     // the scans over very many batches: two sums a tile of kScanTile batches
 };
 
 // ------------------------------------------------------------ batch header
@@ -162,22 +163,51 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint3
     return offset + inc - v;
 }
 
-// Exclusive scans over batches by one workgroup: record slots and CRC work items
-// together, as the two halves of one 64-bit sum.  A thread takes kScanItems
-// consecutive batches, so 8192 batches are one pass.  Only batches of at least
-// min_chunks chunks have CRC work items (the others get their CRC elsewhere).
+// Exclusive scans over batches: record slots and CRC work items together, as the
+// two halves of one 64-bit sum.  A thread takes kScanItems consecutive batches,
+// so a workgroup takes kScanTile in a pass.  Only batches of at least min_chunks
+// chunks have CRC work items (the others get their CRC elsewhere).
+//
+// One workgroup goes through all the batches pass by pass (kScanAll).  From
+// kScanTiledFrom batches on that is too slow (3 us a pass), and the scan is two
+// launches of a workgroup a tile: kScanSum leaves the tile's sum in
+// w.tile_sum, kScanApply starts from the sums of the tiles before its own.
 constexpr int kScanItems = 8;
+constexpr uint32_t kScanTile = 1024 * kScanItems;
+constexpr uint32_t kScanTiledFrom = 4 * kScanTile + 1;
+enum ScanMode : uint32_t { kScanAll = 0, kScanSum = 1, kScanApply = 2 };
+
+// The sum of sums[0 .. count) in every thread of a workgroup of 1024.
+__device__ inline uint64_t tile_sums_before(const uint64_t *sums, uint32_t count, uint32_t pitch, uint64_t *lds16) {
+    uint64_t v = 0;
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) v += sums[(uint64_t)i * pitch];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) lds16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < (blockDim.x >> 6); i++) total += lds16[i];
+    __syncthreads();
+    return total;
+}
 
 __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_columns c, Work w,
-                                                            uint32_t min_chunks, const uint64_t *before) {
+                                                            uint32_t min_chunks, const uint64_t *before,
+                                                            uint32_t mode) {
     __shared__ uint64_t wave_sum[16];
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // records in the low half, work items in the high half.  A call may decode one
     // slice of a blob: its record and header slots then go on where the slice
     // before it ended, whose totals are `before`.
-    uint64_t run = before ? (uint32_t)before[0] : 0;
-    if (threadIdx.x == 0) w.totals[1] = before ? before[1] : 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x * kScanItems) {
+    uint64_t run = before && mode != kScanSum ? (uint32_t)before[0] : 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && mode != kScanSum) w.totals[1] = before ? before[1] : 0;
+    uint32_t first = 0, last = n;
+    if (mode != kScanAll) {
+        first = blockIdx.x * kScanTile;
+        last = n - first < kScanTile ? n : first + kScanTile;
+        if (mode == kScanApply) run += tile_sums_before(w.tile_sum, blockIdx.x, 1, wave_sum);
+    }
+    bool store = mode != kScanSum;
+    for (uint32_t base = first; base < last; base += blockDim.x * kScanItems) {
         uint32_t b0 = base + threadIdx.x * kScanItems;
         uint64_t v[kScanItems], mine = 0;
         // 16-byte loads: the workspace arrays are padded past n, so whole groups can
@@ -223,7 +253,8 @@ __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_c
             cb[i] = (uint32_t)(e >> 32);
             e += v[i];
         }
-        if (b0 + kScanItems <= n && (reinterpret_cast<uintptr_t>(c.rec_base) & 15) == 0) {
+        if (!store) {
+        } else if (b0 + kScanItems <= n && (reinterpret_cast<uintptr_t>(c.rec_base) & 15) == 0) {
 #pragma unroll
             for (int i = 0; i < kScanItems; i += 4)
                 *reinterpret_cast<uint4 *>(c.rec_base + b0 + i) = make_uint4(rb[i], rb[i + 1], rb[i + 2], rb[i + 3]);
@@ -232,14 +263,17 @@ __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_c
             for (int i = 0; i < kScanItems; i++)
                 if (b0 + i < n) c.rec_base[b0 + i] = rb[i];
         }
-        if (b0 < n) {  // chunk_base is a workspace array, padded like the others
+        if (store && b0 < n) {  // chunk_base is a workspace array, padded like the others
 #pragma unroll
             for (int i = 0; i < kScanItems; i += 4)
                 *reinterpret_cast<uint4 *>(w.chunk_base + b0 + i) = make_uint4(cb[i], cb[i + 1], cb[i + 2], cb[i + 3]);
         }
         run += total;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x != 0) return;
+    if (mode == kScanSum) {
+        w.tile_sum[blockIdx.x] = run;
+    } else if (last == n) {
         w.chunk_base[n] = (uint32_t)(run >> 32);
         w.totals[0] = (uint32_t)run;
         w.totals[5] = run >> 32;

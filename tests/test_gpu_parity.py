@@ -475,3 +475,37 @@ def test_encode_of_many_small_batches(codec):
     assert st == C.OK
     assert out[:t.out_bytes].cpu().numpy().tobytes() == want == crc_blob.tobytes()
     assert (out_off.cpu().numpy().astype(np.uint64) == want_off).all()
+
+
+def test_scans_over_more_batches_than_one_workgroup_takes(codec):
+    """From 32769 batches on the scans over batches (record slots and CRC work items
+    in decode, output offsets and skipped batches in encode) run a workgroup a tile
+    of 8192 batches instead of one workgroup for all: same columns and same bytes as
+    the oracle's, malformed batches among them, the last tile a partial one."""
+    import torch
+    small = odd_batches()
+    for case in V["decode_frames"]:
+        frame = bytes(case["frame"])
+        small += [frame[a:b] for a, b in find_batches(frame)]
+    n_b = 5 * 8192 + 77
+    batches = [small[(i * 7 + i // len(small)) % len(small)] for i in range(n_b)]
+    # two batches of 1 MiB values (CRC by chunks on both sides), one of them in the last tile
+    shape, counts, seed = synth.config("c3", 2 / 256)
+    big, big_off, _, _ = synth.make_batches(shape, counts, seed)
+    big = bytes(big)
+    for at, i in ((20000, 0), (n_b - 3, 1)):
+        one = bytearray(big[int(big_off[i]):int(big_off[i + 1])])
+        one[17:21] = struct.pack(">I", oracle.crc32c(bytes(one[21:])))
+        batches[at] = bytes(one)
+    blob = np.frombuffer(b"".join(batches), dtype=np.uint8)
+    off = offsets_of(batches)
+    g, c, totals, cols, d_blob, d_off = check_against_oracle(codec, blob, off)
+    assert totals.n_failed > 0
+    out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
+    t = codec.encode_dev(cols, n_b, d_blob, cols.t["data_off"], out, len(blob) + 64, out_off)
+    st, want, want_off = oracle.encode_columns(c, n_b, blob, c["data_off"])
+    assert st == C.OK
+    assert t.n_failed == totals.n_failed
+    assert (out_off.cpu().numpy().astype(np.uint64) == want_off).all()
+    assert out[:t.out_bytes].cpu().numpy().tobytes() == want
