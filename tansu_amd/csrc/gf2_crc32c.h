@@ -398,6 +398,20 @@ struct BatchStream {
         }
     }
 
+    // pull() with the rows loaded kAhead at a time into the caller's queue, all
+    // before the first is taken: the start of a batch then pays one memory latency
+    // or two, not one a row.
+    __device__ __forceinline__ void pull_wide(uint32_t target, u32x4 (&q)[kAhead]) {
+        target = uni(target);
+        if (target > rows) target = rows;
+#pragma nounroll
+        while (next_row < target) {
+            uint32_t n = uni(target - next_row < (uint32_t)kAhead ? target - next_row : (uint32_t)kAhead);
+            load(q, n);
+            take_loaded(q, n);
+        }
+    }
+
     // the CRC-32C of [lo, hi)
     __device__ __forceinline__ uint32_t finish(const CrcTables *t) {
         pull(rows);

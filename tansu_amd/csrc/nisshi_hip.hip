@@ -933,13 +933,19 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             break;
         }
         PHASE(0)
-        stream.pull(window(pos, S, cap, count - k));  // all there already, but for the first round and a new S
+        u32x4 q[kAhead];
+        // All there already, but for the first round and a new S.  (Through the
+        // queue only with the twelve-row ring: with eight rows at 128 registers the
+        // compiler spills.)
+        if (kRows == 12)
+            stream.pull_wide(window(pos, S, cap, count - k), q);
+        else
+            stream.pull(window(pos, S, cap, count - k));
         PHASE(1)
         uint32_t lanes = count - k < cap ? count - k : cap;
         uint32_t ahead_to = window(pos + lanes * S, S, cap, count - k - lanes);
         uint32_t n_ahead = ahead_to > stream.next_row ? ahead_to - stream.next_row : 0;
         if (n_ahead > (uint32_t)kAhead) n_ahead = kAhead;
-        u32x4 q[kAhead];
         stream.load(q, n_ahead);
         PHASE(2)
         flush();  // the stores of the round before, behind the loads: no wait in between
