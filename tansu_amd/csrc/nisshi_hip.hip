@@ -43,6 +43,7 @@ struct Work {
     uint32_t *resume_pos;   // and its offset in the record data
     uint64_t *totals;       // [0] record slots [1] header slots [2] failed [3] exact [4] out bytes [5] chunks
     uint64_t *tile_sum;     // the scans over very many batches: two sums a tile of kScanTile batches
+    uint32_t *chunk_done;   // encode: the CRC work item has its residue already (from the copy of a long span)
 };
 
 // ------------------------------------------------------------ batch header
@@ -286,9 +287,11 @@ __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_c
 // by binary search in the scan.
 __device__ __forceinline__ void crc_chunk_items(uint32_t first, uint32_t stride, const uint8_t *blob,
                                                 const uint64_t *batch_off, const int32_t *batch_length, uint32_t n,
-                                                uint32_t *crc_out, const Work &w, const CrcTables *t, int lane) {
+                                                uint32_t *crc_out, const Work &w, const CrcTables *t, int lane,
+                                                const uint32_t *done = nullptr) {
     uint32_t total = w.chunk_base[n];
     for (uint32_t item = first; item < total; item += stride) {
+        if (done && done[item]) continue;  // (never the only chunk of a batch)
         uint32_t lo_b = 0, hi_b = n;  // largest b with chunk_base[b] <= item and work items of its own
         while (hi_b - lo_b > 1) {
             uint32_t mid = (lo_b + hi_b) >> 1;
@@ -321,9 +324,9 @@ __device__ __forceinline__ void crc_chunk_items(uint32_t first, uint32_t stride,
 // One wave per work item, as many passes as the grid needs.
 __global__ void crc_chunks_kernel(const uint8_t *blob, const uint64_t *batch_off,
                                   const int32_t *batch_length, uint32_t n, uint32_t *crc_out,
-                                  Work w, const CrcTables *t) {
+                                  Work w, const CrcTables *t, const uint32_t *done) {
     crc_chunk_items(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), gridDim.x * kWavesPerBlock, blob, batch_off,
-                    batch_length, n, crc_out, w, t, threadIdx.x & 63);
+                    batch_length, n, crc_out, w, t, threadIdx.x & 63, done);
 }
 
 // The CRC of a batch of more than one chunk from its chunks' residues:
