@@ -129,7 +129,12 @@ typedef struct nisshi_totals {
 typedef struct nisshi_hip_ctx nisshi_hip_ctx;
 
 /* Create a context on a HIP device; fails with NISSHI_DEVICE_ERROR when no
- * usable gfx950 device is present.  There is no CPU fallback. */
+ * usable gfx950 device is present.  There is no CPU fallback.  Two settings are
+ * read from the environment here: NISSHI_SLICE_BYTES (the slice of the
+ * host-buffer decode, see nisshi_hip_decode) and NISSHI_WIDE_RING_FROM (the mean
+ * batch size in bytes from which the decode kernel streams a batch through
+ * twelve 1 KiB rows of LDS at three waves a SIMD instead of eight at four;
+ * default 65536).  Neither changes any result. */
 int nisshi_hip_ctx_create(int device, nisshi_hip_ctx **ctx);
 void nisshi_hip_ctx_destroy(nisshi_hip_ctx *ctx);
 const char *nisshi_hip_status_str(int status);
