@@ -509,3 +509,31 @@ def test_scans_over_more_batches_than_one_workgroup_takes(codec):
     assert t.n_failed == totals.n_failed
     assert (out_off.cpu().numpy().astype(np.uint64) == want_off).all()
     assert out[:t.out_bytes].cpu().numpy().tobytes() == want
+
+
+def test_encode_long_spans_across_crc_chunks(codec):
+    """Keys and values from just under 16 KiB to over 1 MiB at every alignment: the
+    encoder cuts them at the batch's 64 KiB CRC chunks and takes the CRC of the whole
+    chunks while it copies them, the rest from a pass over the output.  Bytes and CRC
+    must be the oracle's."""
+    import torch
+    rng = np.random.default_rng(11)
+    sizes = [16383, 16384, 16385, 65535, 65536, 65537, 131071, 131072, 140000, 200001, (1 << 20) + 17]
+    batches = []
+    for i, n in enumerate(sizes):
+        recs = [C.Record(0, 0, 0, 0, b"k" * (i * 3 % 17), bytes(rng.integers(0, 256, n, dtype=np.uint8)), [])]
+        if i % 3 == 0:   # a long key as well, a short record between two long ones, headers after
+            recs.append(C.Record(0, 0, 1, 1, None, b"short", [C.Header(b"h", b"v" * 700)]))
+            recs.append(C.Record(0, 0, 2, 2, bytes(rng.integers(0, 256, 70000 + i, dtype=np.uint8)),
+                                 bytes(rng.integers(0, 256, 3 * 65536 + i, dtype=np.uint8)), []))
+        batches.append(build_batch(dict(base_offset=i, last_offset_delta=len(recs) - 1), recs))
+        batches.append(build_batch(dict(base_offset=1000 + i), [C.Record(0, 0, 0, 0, None, b"x" * (i + 1), [])]))
+    blob = np.frombuffer(b"".join(batches), dtype=np.uint8)
+    off = offsets_of(batches)
+    n_b = len(batches)
+    g, c, totals, cols, d_blob, d_off = check_against_oracle(codec, blob, off)
+    assert totals.n_failed == 0 and (g["crc"][:n_b] == g["crc_computed"][:n_b]).all()
+    out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
+    t = codec.encode_dev(cols, n_b, d_blob, cols.t["data_off"], out, len(blob), out_off)
+    assert out[:t.out_bytes].cpu().numpy().tobytes() == blob.tobytes()
