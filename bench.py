@@ -233,7 +233,7 @@ def device_copy_gbs(dev, n_bytes=1 << 30, reps=10):
     return 2 * n_bytes * reps / (t0.elapsed_time(t1) * 1e-3) / 1e9
 
 
-def cpu_baseline(blob, off, n_batches, n_records, budget_s=12.0):
+def cpu_baseline(blob, off, n_batches, n_records, budget_s=20.0):
     """The CPU restatement (oracle/, a port of the reference's algorithm) decoding
     a bounded sample of the same workload on one host core: the first batches of
     the workload, as many as fit the time budget, decoded repeatedly when the
