@@ -537,3 +537,47 @@ def test_encode_long_spans_across_crc_chunks(codec):
     out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
     t = codec.encode_dev(cols, n_b, d_blob, cols.t["data_off"], out, len(blob), out_off)
     assert out[:t.out_bytes].cpu().numpy().tobytes() == blob.tobytes()
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7, 8])
+def test_records_of_many_shapes_in_one_batch(codec, seed):
+    """Records that differ from one to the next (null and long keys, values from
+    empty to 20 KB, up to 20 headers with null values, negative and five-byte
+    deltas, attributes): the walk learns shapes, gives up on them, leaves the LDS
+    ring for global memory and comes back, all within a batch."""
+    import torch
+    rng = np.random.default_rng(seed)
+
+    def blob_of(n):
+        return bytes(rng.integers(0, 256, n, dtype=np.uint8))
+
+    batches = []
+    for b in range(120):
+        recs = []
+        style = b % 4                # 0: every record its own shape; 1: runs of equal shapes; 2: mostly equal; 3: mixed sizes
+        run_shape = None
+        for i in range(int(rng.integers(1, 260))):
+            fresh = style == 0 or run_shape is None or (style == 1 and rng.random() < 0.1) or \
+                (style == 2 and rng.random() < 0.02) or (style == 3 and rng.random() < 0.3)
+            if fresh:
+                big = style == 3 and rng.random() < 0.15
+                run_shape = (None if rng.random() < 0.3 else int(rng.integers(0, 40)),
+                             None if rng.random() < 0.1 else int(rng.integers(7000, 20000) if big else rng.integers(0, 300)),
+                             int(rng.integers(0, 21)) if rng.random() < 0.1 else int(rng.integers(0, 3)))
+            kl, vl, nh = run_shape
+            hdrs = [C.Header(blob_of(int(rng.integers(0, 9))), None if (i + j) % 5 == 0 else blob_of(int(rng.integers(0, 30))))
+                    for j in range(nh)]
+            ts = int(rng.integers(-5, 5)) if rng.random() < 0.9 else int(rng.integers(-2**40, 2**40))
+            od = i if rng.random() < 0.95 else int(rng.integers(-2**31, 2**31))
+            recs.append(C.Record(0, int(rng.integers(0, 2)) * 7, ts, od, None if kl is None else blob_of(kl),
+                                 None if vl is None else blob_of(vl), hdrs))
+        batches.append(build_batch(dict(base_offset=b * 1000, last_offset_delta=len(recs) - 1, attributes=16 * (b % 2)), recs))
+    blob = np.frombuffer(b"".join(batches), dtype=np.uint8)
+    off = offsets_of(batches)
+    n_b = len(batches)
+    g, c, totals, cols, d_blob, d_off = check_against_oracle(codec, blob, off)
+    assert totals.n_failed == 0 and (g["crc"][:n_b] == g["crc_computed"][:n_b]).all()
+    out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
+    t = codec.encode_dev(cols, n_b, d_blob, cols.t["data_off"], out, len(blob), out_off)
+    assert out[:t.out_bytes].cpu().numpy().tobytes() == blob.tobytes()
