@@ -1015,45 +1015,56 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         if (shape.n_checks && shape.size == S && (uint64_t)pos + (uint64_t)lanes * S <= data_len)
             m = fitting(at, lanes);
         if (m == 0) {
-            // ---- where the records start: lane i decodes the length at pos + i * S
-            uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
-            bool in = (uint32_t)lane < lanes && guess64 < data_len;
-            if (!in) start = 0, at = bias;
-            int32_t len = 0;
-            uint32_t used = 0;
-            bool ok = in && fast_varint(ring.read64(at), used, len);
-            // the whole record lies inside the data (this also catches a varint cut short)
-            ok = ok && len >= 0 && (uint64_t)start + used + (uint32_t)len <= data_len;
-            uint32_t size = ok ? used + (uint32_t)len : 0;
-            uint64_t okmask = __ballot(ok);
-            uint64_t same = __ballot(ok && size == S);
-            uint32_t same_size = uni(~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64);
-            if (!(okmask & 1)) {
-                st = kWalkExact;
-            } else if (same_size == 0) {
-                S = uni(size);  // lane 0 is a record, of another size: guess again with that
-                cap = reach(S);
-            } else {
-                // ---- which of them have the shape in hand; learn the first one's if it has not
-                m = fitting(at, same_size);
-                if (m == 0) {
-                    if (lane == 0) learn_shape(tab, ring, pos + bias, S);
-                    lds_order();
-                    const lds_u128 *in4 = htab + kShapeHdrs;
-                    u32x4 a = in4[0], b4 = in4[1], c4 = in4[2];
-                    st = (int)uni(c4.y);
-                    shape.n_checks = st == kWalkDone ? uni(a.x) : 0;
-                    shape.size = S;
-                    shape.n_len = uni(a.y);
-                    shape.length = (int32_t)uni(a.z);
-                    shape.o_od = uni(a.w);
-                    shape.o_key = uni(b4.x);
-                    shape.o_val = uni(b4.y);
-                    shape.klen = (int32_t)uni(b4.z);
-                    shape.vlen = (int32_t)uni(b4.w);
-                    shape.hc = uni(c4.x);
+            // At most twice: when lane 0 is a record of another size and the ring
+            // already holds what a round of that size reads, the round is looked for
+            // again at once instead of in a pass of its own.
+            bool again = true;
+            for (int attempt = 0; attempt < 2 && again; attempt++) {
+                again = false;
+                lanes = count - k < cap ? count - k : cap;
+                start = pos + (uint32_t)lane * S;
+                at = start + bias;
+                // ---- where the records start: lane i decodes the length at pos + i * S
+                uint64_t guess64 = (uint64_t)pos + (uint64_t)lane * S;
+                bool in = (uint32_t)lane < lanes && guess64 < data_len;
+                if (!in) start = 0, at = bias;
+                int32_t len = 0;
+                uint32_t used = 0;
+                bool ok = in && fast_varint(ring.read64(at), used, len);
+                // the whole record lies inside the data (this also catches a varint cut short)
+                ok = ok && len >= 0 && (uint64_t)start + used + (uint32_t)len <= data_len;
+                uint32_t size = ok ? used + (uint32_t)len : 0;
+                uint64_t okmask = __ballot(ok);
+                uint64_t same = __ballot(ok && size == S);
+                uint32_t same_size = uni(~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64);
+                if (!(okmask & 1)) {
+                    st = kWalkExact;
+                } else if (same_size == 0) {
+                    S = uni(size);  // lane 0 is a record, of another size: guess again with that
+                    cap = reach(S);
+                    again = attempt == 0 && S <= kReach && window(pos, S, cap, count - k) <= stream.next_row;
+                } else {
+                    // ---- which of them have the shape in hand; learn the first one's if it has not
                     m = fitting(at, same_size);
-                    if (st == kWalkDone && m == 0) st = kWalkExact;  // cannot happen: a record fits its own shape
+                    if (m == 0) {
+                        if (lane == 0) learn_shape(tab, ring, pos + bias, S);
+                        lds_order();
+                        const lds_u128 *in4 = htab + kShapeHdrs;
+                        u32x4 a = in4[0], b4 = in4[1], c4 = in4[2];
+                        st = (int)uni(c4.y);
+                        shape.n_checks = st == kWalkDone ? uni(a.x) : 0;
+                        shape.size = S;
+                        shape.n_len = uni(a.y);
+                        shape.length = (int32_t)uni(a.z);
+                        shape.o_od = uni(a.w);
+                        shape.o_key = uni(b4.x);
+                        shape.o_val = uni(b4.y);
+                        shape.klen = (int32_t)uni(b4.z);
+                        shape.vlen = (int32_t)uni(b4.w);
+                        shape.hc = uni(c4.x);
+                        m = fitting(at, same_size);
+                        if (st == kWalkDone && m == 0) st = kWalkExact;  // cannot happen: a record fits its own shape
+                    }
                 }
             }
             if (st != kWalkDone) {
