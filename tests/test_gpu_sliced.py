@@ -86,3 +86,27 @@ def test_pinned_buffers_in_slices(codec):
     assert (totals.n_records, totals.n_failed) == (nr, 0)
     st, c, _, _ = oracle.decode_columns(blob, off)
     assert_same(C.unpack(arrays), c, n_b)
+
+
+def test_slices_of_more_batches_than_one_scan_workgroup_takes():
+    """Slices of over 32768 batches each: the scan over batches runs a workgroup a
+    tile and starts from the totals of the slice before it."""
+    old = os.environ.get("NISSHI_SLICE_BYTES")
+    os.environ["NISSHI_SLICE_BYTES"] = str(3_600_000)
+    codec = hip.Codec(0)
+    if old is None:
+        del os.environ["NISSHI_SLICE_BYTES"]
+    else:
+        os.environ["NISSHI_SLICE_BYTES"] = old
+    try:
+        small = odd_batches()
+        for case in V["decode_frames"]:
+            frame = bytes(case["frame"])
+            small += [frame[a:b] for a, b in find_batches(frame)]
+        n_b = 110_000
+        batches = [small[(i * 5 + i // len(small)) % len(small)] for i in range(n_b)]
+        blob = b"".join(batches)
+        assert len(blob) > 2 * 3_600_000 and 3_600_000 / (len(blob) / n_b) > 32768
+        check(codec, blob, offsets_of(batches))
+    finally:
+        codec.close()
