@@ -169,8 +169,8 @@ int nisshi_hip_count_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t bl
  * parallel: a record's headers are contiguous from hdr_base, but the order of
  * runs between batches is not defined and a batch may leave up to 4096 slots of
  * its last run unused (four times that for a batch of 448 KiB and more, or one
- * whose records the streamed walk cannot express: four waves walk it, each with
- * runs of its own), so size hdr_cap with that slack (a batch whose headers do not
+ * whose records the streamed walk cannot express: several waves walk it, each
+ * with runs of its own), so size hdr_cap with that slack (a batch whose headers do not
  * fit gets NISSHI_CAPACITY).  Batches whose records all carry the same number of
  * headers use exactly their header count.  A batch that ends on the sequential
  * walk (totals.n_exact: a record whose length disagrees with its fields, or one

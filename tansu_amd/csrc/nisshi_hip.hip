@@ -457,6 +457,7 @@ struct HeaderRuns {
     uint64_t cap;
     uint32_t run_pos, run_end;   // slots in hand (slot numbers fit 32 bits: the columns hold them so)
     uint32_t total, first_slot;  // of the batch so far
+    uint32_t run_max = kHdrRunMax;  // slots taken ahead at most
 
     // Slots for one round of `m` records, `left` records of the batch following
     // it; lane's record has hc headers (0 in lanes without a record).  Returns
@@ -482,7 +483,7 @@ struct HeaderRuns {
         if (rest) {
             // take enough for the records still to come at this round's density
             uint64_t ahead = (uint64_t)sum * left / m;
-            grab = rest + (uint32_t)(ahead < kHdrRunMax ? ahead : kHdrRunMax);
+            grab = rest + (uint32_t)(ahead < run_max ? ahead : run_max);
             if (lane == 0) new_base = atomicAdd(cursor, (unsigned long long)grab);
             new_base = uni64(new_base);
             if (new_base + grab > cap || new_base + grab > 0xffffffffull) return false;
@@ -540,7 +541,8 @@ constexpr int kWalkGlobal = 2;  // records the streamed walk cannot express: wal
 // batches, records too large for its ring, or of a shape it cannot express.
 // Starts at record k0, byte pos0 of the record data.  Every thread of the
 // workgroup calls it, with the same arguments; all return the same value.
-constexpr int kWalkWaves = 4;
+constexpr int kWalkWaves = 4;      // the usual workgroup
+constexpr int kWalkWavesWide = 8;  // where the call has few batches, so that idle workgroups of 512 threads are few too
 
 struct WalkShare {            // one wave's word to the others, two rounds' worth
     uint32_t taken[2];        // records of the wave that count if the waves before it were full
@@ -553,6 +555,7 @@ struct WalkShare {            // one wave's word to the others, two rounds' wort
     uint32_t full_cap[2];     // the header columns are full
 };
 
+template <int kW>
 __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
                                            HeaderRuns &runs, uint32_t &first_rec, uint32_t k0, uint32_t pos0,
                                            int lane, int wave, WalkShare *share) {
@@ -562,7 +565,7 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
     uint32_t pos = pos0;
     uint32_t S = count > k0 ? (rd.len - pos0) / (count - k0) : 0;
     uint32_t tid = (uint32_t)wave * kWave + (uint32_t)lane;
-    constexpr uint32_t kWide = kWave * kWalkWaves;
+    constexpr uint32_t kWide = kWave * kW;
     int outcome = kWalkDone;
     uint32_t round = 0;
     for (uint32_t k = k0; k < count && outcome == kWalkDone; round++) {
@@ -613,7 +616,7 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
         bool open = true;
         uint32_t new_pos = pos, new_S = S;
 #pragma unroll
-        for (int q = 0; q < kWalkWaves; q++) {
+        for (int q = 0; q < kW; q++) {
             uint32_t tq = share[q].taken[par];
             bool counts = open && tq > 0;
             if (q == wave) my_taken = counts ? tq : 0, taken_before = n_taken;
@@ -676,7 +679,7 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
             bool one_piece;
             uint32_t had = runs.total;
             // what the wave may still have to store in this walk: its share of the records to come
-            uint32_t left = (count - k - taken_before - my_taken) / kWalkWaves;
+            uint32_t left = (count - k - taken_before - my_taken) / kW;
             if (!runs.take(hc, my_taken, left, lane, slot, piece, one_piece)) {
                 no_room = true;
             } else {
@@ -712,7 +715,7 @@ __device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, cons
         __syncthreads();
         uint32_t any_bad = 0, any_full = 0;
 #pragma unroll
-        for (int q = 0; q < kWalkWaves; q++) {
+        for (int q = 0; q < kW; q++) {
             any_bad |= share[q].wrong[par];
             any_full |= share[q].full_cap[par];
         }
@@ -1276,14 +1279,16 @@ __global__ __launch_bounds__(256) void tiny_batch_kernel(const uint8_t *blob, co
 // from global memory; flagged batches from where the streamed walk stopped; the
 // sequential walk for batches that need the reference's exact outcome; and the
 // batch's share of the totals, its status being final here.
+template <int kW>
 struct SlowShare {
-    WalkShare walk[kWalkWaves];
-    uint32_t hdr_total[kWalkWaves], hdr_first_rec[kWalkWaves], hdr_first_slot[kWalkWaves];
+    WalkShare walk[kW];
+    uint32_t hdr_total[kW], hdr_first_rec[kW], hdr_first_slot[kW];
 };
 
+template <int kW>
 __device__ __forceinline__ void slow_batch(const uint8_t *blob, const uint64_t *batch_off, uint32_t b,
                                            const nisshi_columns &c, const Work &w, uint64_t rec_cap, uint64_t hdr_cap,
-                                           const CrcTables *t, SlowShare &sh) {
+                                           const CrcTables *t, SlowShare<kW> &sh) {
     WalkShare *share = sh.walk;
     uint32_t *hdr_total = sh.hdr_total, *hdr_first_rec = sh.hdr_first_rec, *hdr_first_slot = sh.hdr_first_slot;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1300,6 +1305,7 @@ __device__ __forceinline__ void slow_batch(const uint8_t *blob, const uint64_t *
     bool ok = uni(c.status[b]) == NISSHI_OK;
     if (ok && !(flags & kFlagExact) && (big || (flags & kFlagGlobal))) {
         HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
+        runs.run_max = kHdrRunMax * 4 / kW;  // the waves together take no more ahead than four would
         uint32_t k = 0, pos = 0, before = 0, before_slot = 0;
         bool fits = true;
         if (flags & kFlagGlobal) {
@@ -1314,7 +1320,7 @@ __device__ __forceinline__ void slow_batch(const uint8_t *blob, const uint64_t *
             if (lead) c.status[b] = NISSHI_CAPACITY;
         } else {
             uint32_t first_rec = 0xffffffffu;
-            int st = walk_global(blob, b, c, runs, first_rec, k, pos, lane, wave, share);
+            int st = walk_global<kW>(blob, b, c, runs, first_rec, k, pos, lane, wave, share);
             // the batch's headers: every wave took runs of its own
             if (lane == 0) {
                 hdr_total[wave] = runs.total;
@@ -1324,7 +1330,7 @@ __device__ __forceinline__ void slow_batch(const uint8_t *blob, const uint64_t *
             __syncthreads();
             if (lead) {
                 uint32_t total = before, first = 0xffffffffu, slot = before_slot;
-                for (int q = 0; q < kWalkWaves; q++) {
+                for (int q = 0; q < kW; q++) {
                     total += hdr_total[q];
                     if (!before && hdr_first_rec[q] < first) first = hdr_first_rec[q], slot = hdr_first_slot[q];
                 }
@@ -1343,14 +1349,14 @@ __device__ __forceinline__ void slow_batch(const uint8_t *blob, const uint64_t *
 
 // A workgroup a batch; or, where nearly every batch has nothing left (blobs of
 // small batches), per_group batches in turn after a look at all of them at once.
-template <bool kGrouped>
-__global__ __launch_bounds__(kWave * kWalkWaves) void slow_walk_kernel(const uint8_t *blob, const uint64_t *batch_off,
+template <bool kGrouped, int kW>
+__global__ __launch_bounds__(kWave * kW) void slow_walk_kernel(const uint8_t *blob, const uint64_t *batch_off,
                                                                        uint32_t n, nisshi_columns c, Work w,
                                                                        uint64_t rec_cap, uint64_t hdr_cap,
                                                                        const CrcTables *t, uint32_t per_group) {
-    __shared__ SlowShare sh;
+    __shared__ SlowShare<kW> sh;
     if (!kGrouped) {
-        if (blockIdx.x < n) slow_batch(blob, batch_off, blockIdx.x, c, w, rec_cap, hdr_cap, t, sh);
+        if (blockIdx.x < n) slow_batch<kW>(blob, batch_off, blockIdx.x, c, w, rec_cap, hdr_cap, t, sh);
         return;
     }
     uint64_t mine = (uint64_t)blockIdx.x * per_group + threadIdx.x;  // per_group <= the workgroup's threads
@@ -1360,7 +1366,7 @@ __global__ __launch_bounds__(kWave * kWalkWaves) void slow_walk_kernel(const uin
     for (uint32_t i = 0; i < per_group; i++) {
         uint64_t b = (uint64_t)blockIdx.x * per_group + i;
         if (b >= n) return;
-        slow_batch(blob, batch_off, (uint32_t)b, c, w, rec_cap, hdr_cap, t, sh);
+        slow_batch<kW>(blob, batch_off, (uint32_t)b, c, w, rec_cap, hdr_cap, t, sh);
         __syncthreads();  // the next batch reuses the shared state
     }
 }
