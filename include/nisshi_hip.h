@@ -182,6 +182,28 @@ int nisshi_hip_decode_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t b
                           const nisshi_columns *d_cols, uint64_t rec_cap, uint64_t hdr_cap,
                           nisshi_totals *totals, void *stream);
 
+/* nisshi_hip_decode_dev for callers that cannot allocate device memory: code
+ * under HIP graph capture, serving loops that must not call hipMalloc, harnesses
+ * that forbid it.  It has no counterpart in the reference.  Same arguments and
+ * results as nisshi_hip_decode_dev (whose kernels it shares), but the workspace
+ * (per-batch work arrays, the residues of CRC work items, the call's totals) is a
+ * fixed array in the library's device image, 986 880 bytes, which every GPU the
+ * library runs on holds until the process ends, instead of buffers the context
+ * grows with hipMalloc.  The call itself makes no hipMalloc, hipFree or other
+ * allocating call, and records no profiling events.  A call of more than
+ * NISSHI_STATIC_MAX_BATCHES batches or NISSHI_STATIC_MAX_BYTES bytes is refused
+ * with NISSHI_CAPACITY (nisshi_hip_last_error says which limit).  All calls on one
+ * GPU, from any context, share that GPU's array: calls that overlap in time on
+ * one GPU race on it, so keep them on one stream or order them with events.
+ * With totals == NULL the call only enqueues work (use this form under graph
+ * capture); otherwise it waits for the stream. */
+#define NISSHI_STATIC_MAX_BATCHES 16384u
+#define NISSHI_STATIC_MAX_BYTES (512ull << 20)
+int nisshi_hip_decode_dev_static(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
+                                 const uint64_t *d_batch_off, uint32_t n_batches, int by_value,
+                                 const nisshi_columns *d_cols, uint64_t rec_cap, uint64_t hdr_cap,
+                                 nisshi_totals *totals, void *stream);
+
 /* Encode batches from device columns (deflated::Batch::try_from(inflated::Batch)
  * over a frame): record_count, batch_length and crc are recomputed, the length
  * of every record is emitted as stored.  Spans of batch b are read from d_src at

@@ -20,6 +20,7 @@ EXPORTS = [
     "nisshi_hip_ctx_create", "nisshi_hip_ctx_destroy", "nisshi_hip_status_str",
     "nisshi_hip_last_error", "nisshi_frame_split", "nisshi_records_prefix_decode",
     "nisshi_records_prefix_encode", "nisshi_hip_count_dev", "nisshi_hip_decode_dev",
+    "nisshi_hip_decode_dev_static",
     "nisshi_hip_encode_dev", "nisshi_hip_decode", "nisshi_hip_encode", "nisshi_hip_crc32c_dev",
     "nisshi_hip_profile_enable", "nisshi_hip_profile_get", "nisshi_hip_profile_name",
     "nisshi_hip_host_alloc", "nisshi_hip_host_free",
@@ -120,6 +121,7 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_count_dev.argtypes = [vp, vp, u64, vp, u32, ctypes.POINTER(u64), vp]
     lib.nisshi_hip_decode_dev.argtypes = [vp, vp, u64, vp, u32, i32, ctypes.POINTER(C.CColumns),
                                           u64, u64, ctypes.POINTER(Totals), vp]
+    lib.nisshi_hip_decode_dev_static.argtypes = lib.nisshi_hip_decode_dev.argtypes
     lib.nisshi_hip_encode_dev.argtypes = [vp, ctypes.POINTER(C.CColumns), u32, vp, vp, vp, u64, vp,
                                           ctypes.POINTER(Totals), vp]
     lib.nisshi_hip_decode.argtypes = [vp, vp, u64, vp, u32, i32, ctypes.POINTER(C.CColumns), u64,
@@ -313,9 +315,11 @@ class Codec:
         return n.value
 
     def decode_dev(self, d_blob, blob_len: int, d_off, n_batches: int, cols: DeviceColumns,
-                   by_value: bool = True, sync: bool = True) -> Optional[Totals]:
+                   by_value: bool = True, sync: bool = True, static: bool = False) -> Optional[Totals]:
+        """`static`: through nisshi_hip_decode_dev_static, the entry point that allocates nothing."""
         totals = Totals()
-        self._check(self.lib.nisshi_hip_decode_dev(
+        fn = self.lib.nisshi_hip_decode_dev_static if static else self.lib.nisshi_hip_decode_dev
+        self._check(fn(
             self.ctx, d_blob.data_ptr(), blob_len, d_off.data_ptr(), n_batches, int(by_value),
             ctypes.byref(cols.c), cols.rec_cap, cols.hdr_cap,
             ctypes.byref(totals) if sync else None, self._stream()))
