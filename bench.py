@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c2v", "c3", "c4", "c5"])
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-copies", action="store_true",
@@ -128,6 +128,8 @@ def main():
         "config": {
             "workload": {"c1": "C1: 10k batches x 100 records x 100 B values",
                          "c2": "C2: small records, 16 B keys, 64 B values, 2 headers, 1k records/batch",
+                         "c2v": "C2 with sizes that change record to record: values 32-96 B, header values 0-32 B, "
+                                "16 B keys, 2 headers, 1k records/batch",
                          "c3": "C3: large values, 1 MiB values, 4 records/batch",
                          "c4": "C4: mixed topic-partitions (five shapes by p mod 5, 64 batches each), 128 a GPU",
                          "c5": "C5: ragged batches, 1-10k records of 100 B"}[args.workload],

@@ -526,7 +526,8 @@ struct HeaderRuns {
 // How a wave's walk of a batch ended.
 constexpr int kWalkDone = 0;
 constexpr int kWalkExact = 1;   // a record that does not decode, or whose length disagrees: exact_walk
-constexpr int kWalkGlobal = 2;  // records the streamed walk cannot express: walk_global
+constexpr int kWalkGlobal = 2;  // records too large for the LDS ring: walk_global
+constexpr int kWalkChain = 3;   // records whose sizes or shapes change from one to the next: walk_chain
 
 // ---- the walk from global memory
 //
@@ -779,6 +780,29 @@ struct RingView {
         uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, at & 3);
         return ((uint64_t)hi << 32) | lo;
     }
+    // The five bytes at ring offset `ro` (already wrapped: ro < kRingBytes), which is
+    // what a varint of up to five bytes or an attributes byte and a delta of up to
+    // four need: two aligned dwords hold them at any alignment.  Bits above the
+    // fortieth are undefined.
+    __device__ __forceinline__ uint64_t read40(uint32_t ro) const {
+        const lds_u32 *p = ring + (ro >> 2);
+        uint32_t d0 = p[0], d1 = p[1];
+        uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, ro & 3);
+        uint32_t hi = d1 >> (8 * (ro & 3));
+        return ((uint64_t)hi << 32) | lo;
+    }
+    __device__ __forceinline__ uint64_t read64_at(uint32_t ro) const {
+        const lds_u32 *p = ring + (ro >> 2);
+        uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, ro & 3);
+        uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, ro & 3);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    // ring offset of a position less than one ring length past an offset inside the ring
+    __device__ static __forceinline__ uint32_t wrap1(uint32_t x) {
+        uint32_t y = x - (uint32_t)RingCfg<kRows>::kRingBytes;  // wraps to a huge number when x is inside
+        return x < y ? x : y;
+    }
 };
 
 // Learn the shape of the record of `size` bytes at ring position `at0`:
@@ -967,6 +991,11 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     uint32_t S = count ? data_len / count : 0;
     uint32_t cap = reach(S);
     int st = kWalkDone;
+    // rounds in a row that found fewer than kChainBelow of the records they looked
+    // for: after two the sizes are taken to change from record to record, which is
+    // the chained walk's case
+    constexpr uint32_t kChainBelow = 8;
+    uint32_t strikes = 0;
 #ifdef NISSHI_PHASES
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = __builtin_readcyclecounter();
@@ -1076,6 +1105,12 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                 break;
             }
         }
+        strikes = m < kChainBelow && lanes >= 2 * kChainBelow ? strikes + 1 : 0;
+        if (strikes >= 2) {
+            st = kWalkChain;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // as at the end of the pass
+            break;
+        }
         PHASE(5)
         if (m) {
             // ---- the free fields of the records that fit
@@ -1130,6 +1165,216 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     return st;
 }
 
+// ---- the chained walk
+//
+// Records whose sizes change from one to the next cannot be found by guessing a
+// stride.  Here the wave follows the length varints as the reference's loop does
+// (deflated.rs:437-440 with record.rs:254-277), one hop a record: the position is
+// the same in every lane, so the hop runs on the scalar unit (an LDS read of two
+// dwords, the varint, an add) and costs the vector pipe a handful of instructions.  Up
+// to 64 starts, or as many as end inside what the ring holds, go one to a lane;
+// then every lane decodes its record's fields from the ring (Record::decode, any
+// shape: wide varints, any number of headers) and must end where the length said.
+// Starts at record *k_io, byte *pos_io of the record data and leaves there where it
+// stopped.  kWalkExact: a record does not decode as its length says; kWalkGlobal:
+// the next record is larger than the ring.
+
+// LongVarInt::decode at ring offset `ro` for deltas of more than four bytes: up
+// to ten.  False on an eleventh byte (Overflow in the reference).
+template <int kRows>
+__device__ __forceinline__ bool ring_varlong(const RingView<kRows> &ring, uint32_t ro, uint32_t &used, int64_t &out) {
+    uint64_t w = ring.read64_at(ro);
+    uint64_t w2 = ring.read40(RingView<kRows>::wrap1(ro + 8));
+    uint64_t acc = 0;
+    used = 0;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        uint32_t byte = (uint32_t)((i < 8 ? w >> (8 * i) : w2 >> (8 * (i - 8))) & 0xffu);
+        if (!done) {
+            acc |= (uint64_t)(byte & 0x7fu) << (7 * i);
+            used = i + 1;
+            done = !(byte & 0x80u);
+        }
+    }
+    out = (int64_t)(acc >> 1) ^ -(int64_t)(acc & 1u);
+    return done;
+}
+
+template <int kRows>
+__device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, HeaderRuns &runs,
+                                          BatchStream<kRows> &stream, int lane, uint32_t *k_io, uint32_t *pos_io) {
+    typedef RingView<kRows> Ring;
+    uint32_t count = uni(c.record_count[b]);
+    uint64_t rbase = uni(c.rec_base[b]);
+    uint32_t data_len = uni(c.data_len[b]);
+    uint32_t bias = 40 + stream.lo;  // the record data's offset in the stream
+    constexpr uint32_t kRingBytes = RingCfg<kRows>::kRingBytes;
+    constexpr int kAhead = RingCfg<kRows>::kAhead;
+    constexpr uint32_t kReach = kRingBytes - 2 * kRowBytes;  // a round's records end within this of its start
+    Ring ring{stream.ring};
+    uint32_t k = uni(*k_io), pos = uni(*pos_io);
+    int st = kWalkDone;
+    while (k < count) {
+        pos = uni(pos);
+        k = uni(k);
+        // the ring holds the rows up to `have`; this round reads up to kReach + 64 bytes from pos
+        u32x4 q[kAhead];
+        uint32_t target = stream.row_after(bias + pos + kReach + 64);
+        if (kRows == 12)
+            stream.pull_wide(target, q);
+        else
+            stream.pull(target);
+        // the rows after those, asked for now and moved in at the end of the pass, as
+        // far as the next round's start then allows
+        uint32_t n_ahead = stream.rows - stream.next_row;
+        if (n_ahead > (uint32_t)kAhead) n_ahead = kAhead;
+        stream.load(q, n_ahead);
+        lds_order();
+        // ---- the hops: one record start a lane
+        uint32_t want = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
+        uint32_t limit = data_len - pos < kReach ? data_len : pos + kReach;
+        uint32_t p = pos, n = 0, ro = RingCfg<kRows>::wrap(pos + bias);
+        uint32_t my_start = 0;
+        int stop = 0;  // 1: the record does not lie inside the data; 2: it is larger than the ring
+        while (n < want) {
+            if (p >= data_len) {
+                stop = 1;
+                break;
+            }
+            const lds_u32 *w = ring.ring + (ro >> 2);
+            uint32_t d0 = uni(w[0]), d1 = uni(w[1]);
+            uint64_t v = (((uint64_t)d1 << 32) | d0) >> (8 * (ro & 3));
+            uint32_t used;
+            int32_t len;
+            bool ok = fast_varint(v, used, len);
+            uint32_t size = used + (uint32_t)len;
+            if (!ok || len < 0 || size > data_len - p) {
+                stop = 1;
+                break;
+            }
+            if (size > limit - p) {
+                if (n == 0) stop = 2;
+                break;
+            }
+            my_start = (uint32_t)lane == n ? p : my_start;
+            n++;
+            p += size;
+            ro += size;
+            ro = ro >= kRingBytes ? ro - kRingBytes : ro;
+        }
+        n = uni(n);
+        if (stop) {
+            st = stop == 1 ? kWalkExact : kWalkGlobal;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // the rows asked for are dropped
+            break;
+        }
+        // ---- a lane a record: the fields
+        bool live = (uint32_t)lane < n;
+        uint32_t start = live ? my_start : pos;
+        uint32_t ro0 = RingCfg<kRows>::wrap(start + bias);
+        RecordFields f;
+        uint32_t used, q_used;
+        bool ok = fast_varint(ring.read40(ro0), used, f.length) && live;  // known to be good in live lanes
+        uint32_t end = start + used + (uint32_t)f.length;
+        uint32_t o = used;  // offset in the record
+        auto at = [&](uint32_t off) { return Ring::wrap1(ro0 + off); };
+        {
+            uint64_t w0 = ring.read40(at(o));  // attributes, then the timestamp delta
+            f.attributes = (uint32_t)w0 & 0xffu;
+            o += 1;
+            bool quick = fast_varlong((uint32_t)(w0 >> 8), q_used, f.timestamp_delta);
+            if (!quick) ok = ring_varlong(ring, at(o), q_used, f.timestamp_delta) && ok;
+            o += q_used;
+        }
+        uint32_t body = end - start;  // the record's bytes, its length varint included
+        ok = fast_varint(ring.read40(at(o)), q_used, f.offset_delta) && ok;
+        o += q_used;
+        ok = fast_varint(ring.read40(at(o)), q_used, f.key_len) && ok;
+        o += q_used;
+        f.key_off = start + o;
+        ok = ok && f.key_len >= -1 && o <= body && (uint32_t)(f.key_len < 0 ? 0 : f.key_len) <= body - o;
+        o += ok && f.key_len > 0 ? (uint32_t)f.key_len : 0u;
+        ok = fast_varint(ring.read40(at(o)), q_used, f.val_len) && ok;
+        o += ok ? q_used : 0u;
+        f.val_off = start + o;
+        ok = ok && f.val_len >= -1 && o <= body && (uint32_t)(f.val_len < 0 ? 0 : f.val_len) <= body - o;
+        o += ok && f.val_len > 0 ? (uint32_t)f.val_len : 0u;
+        ok = fast_varint(ring.read40(at(o)), q_used, f.hdr_count) && ok;
+        o += ok ? q_used : 0u;
+        // a header is at least two bytes: a count the record cannot hold is an error
+        ok = ok && f.hdr_count >= 0 && o <= body && (uint32_t)f.hdr_count <= (body - o) / 2;
+        uint32_t hc = live && ok ? (uint32_t)f.hdr_count : 0;
+        uint32_t slot = 0;
+        bool no_room = false;
+        if (__any(hc != 0)) {
+            uint32_t piece;
+            bool one_piece;
+            if (!runs.take(hc, n, count - k - n, lane, slot, piece, one_piece)) {
+                no_room = true;
+            } else {
+                uint32_t most = 0;
+                {
+                    uint32_t m = hc;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        uint32_t t = (uint32_t)__shfl_xor((int)m, d, 64);
+                        m = m > t ? m : t;
+                    }
+                    most = uni(m);
+                }
+                for (uint32_t j = 0; j < most; j++) {
+                    bool mine = j < hc && ok;
+                    int32_t kl = 0, vl = 0;
+                    uint32_t ko, vo, n1, n2;
+                    bool good = fast_varint(ring.read40(at(mine ? o : 0u)), n1, kl);
+                    uint32_t o1 = o + n1;
+                    ko = start + o1;
+                    good = good && kl >= -1 && o1 <= body && (uint32_t)(kl < 0 ? 0 : kl) <= body - o1;
+                    o1 += good && kl > 0 ? (uint32_t)kl : 0u;
+                    good = fast_varint(ring.read40(at(mine && good ? o1 : 0u)), n2, vl) && good;
+                    o1 += n2;
+                    vo = start + o1;
+                    good = good && vl >= -1 && o1 <= body && (uint32_t)(vl < 0 ? 0 : vl) <= body - o1;
+                    o1 += good && vl > 0 ? (uint32_t)vl : 0u;
+                    if (mine) {
+                        ok = good;
+                        if (good) {
+                            o = o1;
+                            store_header(c, slot + j, ko, kl, vo, vl);
+                        }
+                    }
+                }
+            }
+        }
+        if (no_room) {
+            if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+            k = count;  // ends the walk, the batch has its status
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            break;
+        }
+        // the fields must end exactly where the length said
+        if (__any(live && (!ok || o != body))) {
+            st = kWalkExact;
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            break;
+        }
+        if (live) store_record(c, rbase + k, (uint32_t)lane, f, slot);
+        k += n;
+        pos = p;
+        lds_order();
+        // ---- the rows asked for at the top, as far as the next round may hold them
+        uint32_t need = k < count ? stream.row_after(bias + pos + kReach + 64) : stream.next_row;
+        uint32_t n_take = need > stream.next_row ? need - stream.next_row : 0;
+        stream.take_loaded(q, n_take < n_ahead ? n_take : n_ahead);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // no load is outstanding across the loop edge
+        lds_order();
+    }
+    *k_io = k;
+    *pos_io = pos;
+    return st;
+}
+
 // One wave per batch: CRC-32C of the batch streamed just ahead of the record
 // walk through an LDS ring, so the batch is read from HBM once.  Batches of
 // kBigChunks chunks or more get their CRC from crc_chunks_kernel instead (one
@@ -1173,6 +1418,8 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
         HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
         uint32_t k = 0, pos = 0;
         int st = walk_streamed(b, c, runs, stream, (lds_u128 *)shape_tab, lane, &k, &pos);
+        // records of changing sizes, or of shapes the compares cannot express: hop by hop
+        if (st == kWalkChain || st == kWalkGlobal) st = walk_chain(b, c, runs, stream, lane, &k, &pos);
         if (lane == 0) {
             c.hdr_count[b] = runs.total;
             c.hdr_base[b] = runs.first_slot;

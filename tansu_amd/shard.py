@@ -47,6 +47,9 @@ def make_shard(workload: str, scale: float, rank: int, world: int = 1):
     if workload == "c4":
         return mixed_shard(scale, rank, world)
     shape, counts, seed = synth.config(workload, scale)
+    if workload == "c2v":
+        blob, off, n_records, n_headers = synth.make_var_batches(len(counts), int(counts[0]), shard_seed(seed, rank))
+        return shape, blob, off, n_records, n_headers, len(counts)
     blob, off, n_records, n_headers = synth.make_batches(shape, counts, shard_seed(seed, rank))
     return shape, blob, off, n_records, n_headers, len(counts)
 

@@ -182,6 +182,69 @@ def make_batches(shape: Shape, counts, seed: int, template: Template = None):
     return blob, off, n_records, n_records * shape.n_headers
 
 
+def _uniform_ints(seed: int, n: int, lo: int, hi: int) -> np.ndarray:
+    """n integers uniform in [lo, hi] from the splitmix64 stream of `seed`."""
+    return (lo + (splitmix64(seed, n) >> np.uint64(11)) % np.uint64(hi - lo + 1)).astype(np.int64)
+
+
+def make_var_batches(n_batches: int, records: int, seed: int, key_len: int = 16, val_range=(32, 96),
+                     n_headers: int = 2, hkey_len: int = 8, hval_range=(0, 32)):
+    """Batches whose records differ in size from one to the next: every record
+    draws its value length from val_range and the value length of each of its
+    headers from hval_range (both inclusive), everything else as in make_batches
+    (offset_delta = timestamp_delta = index in the batch, random payload bytes).
+    Returns (blob, batch_off, n_records, n_headers); CRC fields are zero.
+
+    The blob is filled with random bytes first and the structural bytes (lengths,
+    counts, deltas, attributes) are written over them, so the whole input is built
+    by a handful of array operations."""
+    n = n_batches * records
+    assert records < (1 << 13) and max(key_len, val_range[1], hkey_len, hval_range[1]) < (1 << 13)
+
+    def zz_size(v):                       # bytes of the zigzag varint of v (v < 2^13, or -1)
+        z = np.where(v < 0, 1, 2 * v)
+        return np.where(z < 128, 1, 2).astype(np.int64)
+
+    idx = np.tile(np.arange(records, dtype=np.int64), n_batches)
+    vl = _uniform_ints(seed + 1, n, *val_range)
+    hvl = _uniform_ints(seed + 2, n * max(n_headers, 1), *hval_range).reshape(n, max(n_headers, 1))[:, :n_headers]
+    kl = np.full(n, key_len, dtype=np.int64)
+    hkl = np.full(n, hkey_len, dtype=np.int64)
+    hc = np.full(n, n_headers, dtype=np.int64)
+    # field sizes, in wire order; a negative length is a null span of no bytes
+    pieces = [("var", idx), ("var", idx), ("var", kl), ("pay", kl), ("var", vl), ("pay", vl), ("var", hc)]
+    for j in range(n_headers):
+        pieces += [("var", hkl), ("pay", hkl), ("var", hvl[:, j]), ("pay", hvl[:, j])]
+    body = np.ones(n, dtype=np.int64)     # the attributes byte
+    for kind, v in pieces:
+        body += zz_size(v) if kind == "var" else np.maximum(v, 0)
+    rec = zz_size(body) + body
+    rec_end = np.cumsum(rec.reshape(n_batches, records), axis=1)
+    data_len = rec_end[:, -1]
+    off = np.zeros(n_batches + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(61 + data_len)
+    blob = random_bytes(seed, int(off[-1])).copy()
+    starts = (off[:-1].astype(np.int64)[:, None] + 61 + rec_end - rec.reshape(n_batches, records)).reshape(-1)
+
+    def put_var(pos, v):                  # zigzag varints of one or two bytes at pos
+        z = np.where(v < 0, 1, 2 * v)
+        two = z >= 128
+        blob[pos] = np.where(two, (z & 0x7F) | 0x80, z).astype(np.uint8)
+        blob[pos[two] + 1] = (z[two] >> 7).astype(np.uint8)
+        return pos + np.where(two, 2, 1)
+
+    pos = put_var(starts, body)
+    blob[pos] = 0                         # attributes
+    pos = pos + 1
+    for kind, v in pieces:
+        pos = put_var(pos, v) if kind == "var" else pos + np.maximum(v, 0)
+    assert (pos == starts + rec).all()
+    for b in range(n_batches):
+        s = int(off[b])
+        blob[s:s + 61] = np.frombuffer(batch_header(b * records, int(data_len[b]), records), dtype=np.uint8)
+    return blob, off, n, n * n_headers
+
+
 def patch_crc(blob: np.ndarray, batch_off: np.ndarray, crc: np.ndarray) -> None:
     """Write per-batch CRC values (big-endian) into bytes 17..21 of every batch."""
     be = np.ascontiguousarray(crc, dtype=np.uint32).astype(">u4").view(np.uint8).reshape(-1, 4)
@@ -203,6 +266,8 @@ def config(name: str, scale: float = 1.0):
         return C1_SHAPE, np.full(max(1, int(10_000 * scale)), 100), SEED_BASE + 1
     if name == "c2":   # small records: 16 B keys, 64 B values, 2 headers, 1k records/batch
         return C2_SHAPE, np.full(max(1, int(8_192 * scale)), 1000), SEED_BASE + 2
+    if name == "c2v":  # C2 with sizes that change record to record: see make_var_batches
+        return None, np.full(max(1, int(8_192 * scale)), 1000), SEED_BASE + 6
     if name == "c3":   # large values: 1 MiB values, 4 records/batch
         return C3_SHAPE, np.full(max(1, int(256 * scale)), 4), SEED_BASE + 3
     if name == "c5":   # ragged: records per batch log-uniform in [1, 10 000], 100 B values

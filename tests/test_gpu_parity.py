@@ -177,6 +177,60 @@ def test_synthetic_vs_oracle(codec, name, scale):
     assert got.tobytes() == want == blob.tobytes()
 
 
+def test_records_of_changing_sizes_vs_oracle(codec):
+    """C2 with value and header-value lengths drawn per record: no two neighbours
+    have the same size, so record starts can only be found by following the length
+    varints.  Columns against the oracle, then the re-encode against the input."""
+    import torch
+    blob, off, nr, nh = synth.make_var_batches(24, 1000, synth.SEED_BASE + 6)
+    crc_patch(codec, blob, off)
+    g, c, totals, cols, d_blob, d_off = check_against_oracle(codec, blob, off)
+    assert (totals.n_failed, totals.n_exact, totals.n_records) == (0, 0, nr)
+    assert int(g["hdr_count"].sum()) == nh and (g["crc"] == g["crc_computed"]).all()
+    assert len(np.unique(c["val_len"])) == 65 and len(np.unique(c["hval_len"])) == 33
+    n_b = len(off) - 1
+    out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
+    t = codec.encode_dev(cols, n_b, d_blob, cols.t["data_off"], out, len(blob), out_off)
+    assert out[:t.out_bytes].cpu().numpy().tobytes() == blob.tobytes()
+
+
+def test_changing_sizes_with_a_wrong_length_and_a_large_record(codec):
+    """The chained walk's ways out: a record whose length disagrees with its fields
+    deep inside a batch (the sequential walk takes over and accepts it, as the
+    reference does), a record larger than the LDS ring between small ones (the walk
+    from global memory takes over), and a batch whose count runs past its data."""
+    rng = np.random.default_rng(17)
+
+    def recs(n, big_at=None):
+        out = []
+        for i in range(n):
+            v = bytes(rng.integers(0, 256, 20000 if i == big_at else int(rng.integers(0, 120)), dtype=np.uint8))
+            hdrs = [C.Header(b"k%d" % j, bytes(rng.integers(0, 256, int(rng.integers(0, 12)), dtype=np.uint8)))
+                    for j in range(int(rng.integers(0, 4)))]
+            out.append(C.Record(0, 0, i, i, None if i % 7 == 0 else b"key%d" % i, v, hdrs))
+        return out
+
+    plain = build_batch(dict(base_offset=0, last_offset_delta=299), recs(300))
+    big = build_batch(dict(base_offset=300, last_offset_delta=399), recs(400, big_at=250))
+    wrong = bytearray(build_batch(dict(base_offset=700, last_offset_delta=199), recs(200)))
+    # the length varint of a record far inside: find record 150's start through the oracle
+    st, c, _, _ = oracle.decode_columns(bytes(wrong), offsets_of([bytes(wrong)]))
+    at = 61 + int(c["key_off"][150]) - 1          # its key length varint (one byte: short keys)
+    while wrong[at] != (2 * len(b"key150")):      # step back over ts/od varints to be safe
+        at -= 1
+    rec_start = at - 1 - len(synth.varint(150)) * 2 - len(synth.varint(int(c["length"][150])))
+    assert len(synth.varint(int(c["length"][150]))) == 2
+    wrong[rec_start] ^= 0x02                      # length changes by one: it now disagrees with the fields
+    short = bytearray(build_batch(dict(base_offset=900, last_offset_delta=99), recs(100)))
+    short[57:61] = struct.pack(">I", 101)         # one record more than the data holds
+    batches = [plain, big, bytes(wrong), bytes(short), plain]
+    blob = np.frombuffer(b"".join(batches), dtype=np.uint8)
+    g, c, totals, *_ = check_against_oracle(codec, blob, offsets_of(batches))
+    assert list(c["status"]) == [C.OK, C.OK, C.OK, C.TRY_GET, C.OK]
+    assert totals.n_exact >= 2 and totals.n_failed == 1
+
+
 def test_mixed_partitions_round_trip(codec):
     import torch
     for blob, off, nr, nh in synth.mixed_partitions(10, 3):
