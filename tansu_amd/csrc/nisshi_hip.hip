@@ -1179,6 +1179,109 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
 // stopped.  kWalkExact: a record does not decode as its length says; kWalkGlobal:
 // the next record is larger than the ring.
 
+// The hops of the chained walk over records whose length varint has kBytes bytes
+// (1: records under 64 bytes, 2: under 8 KiB), written by hand: the scalar unit
+// is one to a CU, shared by all its waves, so every scalar instruction of a hop
+// is a cycle no other wave of the CU gets; the compiler's form of this loop took
+// about sixty, this one takes seventeen (two-byte lengths) or fourteen.
+//
+// The loop runs with one lane enabled, the lane whose record is being looked at:
+// EXEC starts as lane n0 and moves up a lane a hop, so that the vector moves
+// below write that lane only.  A hop: the two aligned dwords that hold the
+// length (vector address arithmetic and LDS reads under the one-lane EXEC), the
+// bytes shifted into place and read back to a scalar; the form of the length
+// (continuation bits as expected, not negative: else out); its value plus kBytes
+// is the record's size; out if that is more than `left`, the bytes up to the
+// round's limit; the lane notes `left` (its start, counted back from the limit);
+// `left` and the ring offset `ro` move on; `rem`, the records still wanted less
+// one, counts down and ends the loop by its borrow.
+// Leaves EXEC as it found it.  Records found: the starting rem - the final rem
+// (in 32-bit arithmetic: the borrow leaves rem at 0xFFFFFFFF).
+template <int kBytes, uint32_t kRing>
+__device__ __forceinline__ void hop_loop(uint32_t ring_at, uint32_t n0, uint32_t &ro, uint32_t &left, uint32_t &rem,
+                                         uint32_t &my_left) {
+    static_assert(kBytes == 1 || kBytes == 2, "one- and two-byte lengths only");
+    uint32_t va, vsh, d0, d1, vlo, lo, t, a, h;
+    uint64_t save;
+    if (kBytes == 2) {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "s_lshl_b64 exec, 1, %[n0]\n"
+            "1:\n\t"
+            "v_add_u32_e32 %[va], %[ro], %[base]\n\t"
+            "v_and_b32_e32 %[vsh], 3, %[va]\n\t"
+            "v_and_b32_e32 %[va], -4, %[va]\n\t"
+            "ds_read_b32 %[d0], %[va]\n\t"
+            "ds_read_b32 %[d1], %[va] offset:4\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_alignbyte_b32 %[vlo], %[d1], %[d0], %[vsh]\n\t"
+            "s_nop 0\n\t"                              // a lane read of a register a vector instruction has just written needs a wait state
+            "v_readfirstlane_b32 %[lo], %[vlo]\n\t"
+            "s_and_b32 %[t], %[lo], 0x8081\n\t"      // second byte ends the varint, first continues, value not negative
+            "s_cmp_lg_u32 %[t], 0x80\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_bfe_u32 %[a], %[lo], 0x60001\n\t"     // zigzag: the value is the 13 bits above bit 0
+            "s_bfe_u32 %[h], %[lo], 0x70008\n\t"
+            "s_lshl_b32 %[h], %[h], 6\n\t"
+            "s_add_u32 %[a], %[a], %[h]\n\t"
+            "s_add_u32 %[a], %[a], 2\n\t"
+            "s_sub_u32 %[t], %[left], %[a]\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "v_mov_b32_e32 %[st], %[left]\n\t"
+            "s_mov_b32 %[left], %[t]\n\t"
+            "s_add_u32 %[ro], %[ro], %[a]\n\t"
+            "s_sub_u32 %[t], %[ro], %[ring]\n\t"
+            "s_min_u32 %[ro], %[ro], %[t]\n\t"
+            "s_lshl_b64 exec, exec, 1\n\t"
+            "s_sub_u32 %[rem], %[rem], 1\n\t"
+            "s_cbranch_scc0 1b\n"
+            "2:\n\t"
+            "s_mov_b64 exec, %[save]\n\t"
+            : [ro] "+s"(ro), [left] "+s"(left), [rem] "+s"(rem), [st] "+v"(my_left), [va] "=&v"(va), [vsh] "=&v"(vsh),
+              [d0] "=&v"(d0), [d1] "=&v"(d1), [vlo] "=&v"(vlo), [lo] "=&s"(lo), [t] "=&s"(t), [a] "=&s"(a),
+              [h] "=&s"(h), [save] "=&s"(save)
+            : [base] "v"(ring_at), [n0] "s"(n0), [ring] "i"(kRing)
+            : "memory", "scc");
+    } else {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "s_lshl_b64 exec, 1, %[n0]\n"
+            "1:\n\t"
+            "v_add_u32_e32 %[va], %[ro], %[base]\n\t"
+            "v_and_b32_e32 %[vsh], 3, %[va]\n\t"
+            "v_and_b32_e32 %[va], -4, %[va]\n\t"
+            "ds_read_b32 %[d0], %[va]\n\t"
+            "ds_read_b32 %[d1], %[va] offset:4\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_alignbyte_b32 %[vlo], %[d1], %[d0], %[vsh]\n\t"
+            "s_nop 0\n\t"                              // a lane read of a register a vector instruction has just written needs a wait state
+            "v_readfirstlane_b32 %[lo], %[vlo]\n\t"
+            "s_and_b32 %[t], %[lo], 0x81\n\t"        // the first byte ends the varint, value not negative
+            "s_cmp_lg_u32 %[t], 0\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_bfe_u32 %[a], %[lo], 0x60001\n\t"
+            "s_add_u32 %[a], %[a], 1\n\t"
+            "s_sub_u32 %[t], %[left], %[a]\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "v_mov_b32_e32 %[st], %[left]\n\t"
+            "s_mov_b32 %[left], %[t]\n\t"
+            "s_add_u32 %[ro], %[ro], %[a]\n\t"
+            "s_sub_u32 %[t], %[ro], %[ring]\n\t"
+            "s_min_u32 %[ro], %[ro], %[t]\n\t"
+            "s_lshl_b64 exec, exec, 1\n\t"
+            "s_sub_u32 %[rem], %[rem], 1\n\t"
+            "s_cbranch_scc0 1b\n"
+            "2:\n\t"
+            "s_mov_b64 exec, %[save]\n\t"
+            : [ro] "+s"(ro), [left] "+s"(left), [rem] "+s"(rem), [st] "+v"(my_left), [va] "=&v"(va), [vsh] "=&v"(vsh),
+              [d0] "=&v"(d0), [d1] "=&v"(d1), [vlo] "=&v"(vlo), [lo] "=&s"(lo), [t] "=&s"(t), [a] "=&s"(a),
+              [save] "=&s"(save)
+            : [base] "v"(ring_at), [n0] "s"(n0), [ring] "i"(kRing)
+            : "memory", "scc");
+        (void)h;
+    }
+}
+
 // LongVarInt::decode at ring offset `ro` for deltas of more than four bytes: up
 // to ten.  False on an eleventh byte (Overflow in the reference).
 template <int kRows>
@@ -1215,9 +1318,15 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
     Ring ring{stream.ring};
     uint32_t k = uni(*k_io), pos = uni(*pos_io);
     int st = kWalkDone;
+#ifdef NISSHI_PHASES
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tmark = __builtin_readcyclecounter();
+    uint32_t n_rounds = 0, k_first = k;
+#endif
     while (k < count) {
         pos = uni(pos);
         k = uni(k);
+        PHASE(0)
         // the ring holds the rows up to `have`; this round reads up to kReach + 64 bytes from pos
         u32x4 q[kAhead];
         uint32_t target = stream.row_after(bias + pos + kReach + 64);
@@ -1231,11 +1340,38 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
         if (n_ahead > (uint32_t)kAhead) n_ahead = kAhead;
         stream.load(q, n_ahead);
         lds_order();
+        PHASE(1)
         // ---- the hops: one record start a lane
         uint32_t want = count - k < (uint32_t)kWave ? count - k : (uint32_t)kWave;
         uint32_t limit = data_len - pos < kReach ? data_len : pos + kReach;
         uint32_t p = pos, n = 0, ro = RingCfg<kRows>::wrap(pos + bias);
         uint32_t my_start = 0;
+        {
+            // lengths of one byte and of two, each by a loop of its own (hop_loop); a
+            // change of form, or anything else that stops a loop, is looked at here
+            uint32_t my_left = 0;  // the lane's start as the distance to `limit`
+            uint32_t ring_at = (uint32_t)(uintptr_t)ring.ring;
+            for (int pass = 0; pass < 4 && n < want && p < limit; pass++) {
+                const lds_u32 *w = ring.ring + (ro >> 2);
+                uint32_t d0 = uni(w[0]), d1 = uni(w[1]);
+                uint32_t lo = (uint32_t)((((uint64_t)d1 << 32) | d0) >> (8 * (ro & 3)));
+                uint32_t left = limit - p, rem = want - n - 1;
+                if (!(lo & 0x80u))
+                    hop_loop<1, kRingBytes>(ring_at, n, ro, left, rem, my_left);
+                else if (!(lo & 0x8000u))
+                    hop_loop<2, kRingBytes>(ring_at, n, ro, left, rem, my_left);
+                else
+                    break;
+                uint32_t found = want - n - 1 - rem;
+                if (found == 0) break;
+                n += found;
+                p = limit - left;
+            }
+            my_start = limit - my_left;
+        }
+        PHASE(2)
+        // why the loop ended, when it did not find all it wanted: the general decode
+        // of the length at p decides
         int stop = 0;  // 1: the record does not lie inside the data; 2: it is larger than the ring
         while (n < want) {
             if (p >= data_len) {
@@ -1248,19 +1384,20 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
             uint32_t used;
             int32_t len;
             bool ok = fast_varint(v, used, len);
-            uint32_t size = used + (uint32_t)len;
-            if (!ok || len < 0 || size > data_len - p) {
+            uint32_t sz = used + (uint32_t)len;
+            if (!ok || len < 0 || sz > data_len - p) {
                 stop = 1;
                 break;
             }
-            if (size > limit - p) {
+            if (sz > limit - p) {
                 if (n == 0) stop = 2;
                 break;
             }
+            // a length of three bytes and more that fits: take it and go on one by one
             my_start = (uint32_t)lane == n ? p : my_start;
             n++;
-            p += size;
-            ro += size;
+            p += sz;
+            ro += sz;
             ro = ro >= kRingBytes ? ro - kRingBytes : ro;
         }
         n = uni(n);
@@ -1269,6 +1406,7 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
             __builtin_amdgcn_s_waitcnt(0x0F70);  // the rows asked for are dropped
             break;
         }
+        PHASE(3)
         // ---- a lane a record: the fields
         bool live = (uint32_t)lane < n;
         uint32_t start = live ? my_start : pos;
@@ -1307,6 +1445,7 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
         uint32_t hc = live && ok ? (uint32_t)f.hdr_count : 0;
         uint32_t slot = 0;
         bool no_room = false;
+        PHASE(4)
         if (__any(hc != 0)) {
             uint32_t piece;
             bool one_piece;
@@ -1359,17 +1498,28 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
             __builtin_amdgcn_s_waitcnt(0x0F70);
             break;
         }
+        PHASE(5)
         if (live) store_record(c, rbase + k, (uint32_t)lane, f, slot);
         k += n;
         pos = p;
         lds_order();
+        PHASE(6)
+#ifdef NISSHI_PHASES
+        n_rounds++;
+#endif
         // ---- the rows asked for at the top, as far as the next round may hold them
         uint32_t need = k < count ? stream.row_after(bias + pos + kReach + 64) : stream.next_row;
         uint32_t n_take = need > stream.next_row ? need - stream.next_row : 0;
         stream.take_loaded(q, n_take < n_ahead ? n_take : n_ahead);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // no load is outstanding across the loop edge
         lds_order();
+        PHASE(7)
     }
+#ifdef NISSHI_PHASES
+    if (lane == 0 && (b % 1024) == 7)
+        printf("chain b=%u rounds=%u records=%u other=%lu pull=%lu hops=%lu tail=%lu fields=%lu headers=%lu store=%lu take=%lu\n", b,
+               n_rounds, k - k_first, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+#endif
     *k_io = k;
     *pos_io = pos;
     return st;
