@@ -18,6 +18,7 @@
 // libnisshi_hip.so.
 #pragma once
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -146,9 +147,111 @@ struct Record {
     }
 };
 
+// ByteSize of the primitives (primitive/varint.rs:186-196, 379-389, 546-556;
+// record/codec.rs:34-45): the bytes of a zigzag varint of 32 and of 64 bits, of an
+// unsigned varint, and of a nullable span behind its length.
+inline size_t varint_size(int32_t v) {
+    uint32_t z = (uint32_t(v) << 1) ^ uint32_t(v >> 31);
+    size_t n = 1;
+    while (z >= 0x80) z >>= 7, n++;
+    return n;
+}
+inline size_t long_varint_size(int64_t v) {
+    uint64_t z = (uint64_t(v) << 1) ^ uint64_t(v >> 63);
+    size_t n = 1;
+    while (z >= 0x80) z >>= 7, n++;
+    return n;
+}
+inline size_t unsigned_varint_size(uint32_t v) {
+    size_t n = 1;
+    while (v >= 0x80) v >>= 7, n++;
+    return n;
+}
+inline size_t octets_size(const std::optional<Bytes> &b) {
+    return b ? varint_size(int32_t(b->len())) + b->len() : varint_size(-1);
+}
+// Header::size_in_bytes, header.rs:31-41
+inline size_t header_size(const Header &h) { return octets_size(h.key) + octets_size(h.value); }
+
+// record::Builder, record.rs:329-421.  build() is TryFrom<Builder> for Record
+// (record.rs:298-314): `length` becomes the size of the record's body, which
+// excludes the length prefix itself.
+struct Builder {
+    uint8_t attributes_ = 0;
+    int64_t timestamp_delta_ = 0;
+    int32_t offset_delta_ = 0;
+    std::optional<Bytes> key_, value_;
+    std::vector<Header> headers_;
+
+    Builder attributes(uint8_t v) && { attributes_ = v; return std::move(*this); }
+    Builder timestamp_delta(int64_t v) && { timestamp_delta_ = v; return std::move(*this); }
+    Builder offset_delta(int32_t v) && { offset_delta_ = v; return std::move(*this); }
+    Builder key(std::optional<Bytes> v) && { key_ = std::move(v); return std::move(*this); }
+    Builder value(std::optional<Bytes> v) && { value_ = std::move(v); return std::move(*this); }
+    Builder header(Header h) && { headers_.push_back(std::move(h)); return std::move(*this); }
+
+    // ByteSize for Builder, record.rs:363-372
+    size_t size_in_bytes() const {
+        size_t n = 1 + long_varint_size(timestamp_delta_) + varint_size(offset_delta_) + octets_size(key_) +
+                   octets_size(value_) + varint_size(int32_t(headers_.size()));
+        for (const Header &h : headers_) n += header_size(h);
+        return n;
+    }
+    Result<Record> build() const {
+        size_t n = size_in_bytes();
+        if (n > 0x7fffffffu) return Error::from_status(NISSHI_TRY_FROM_INT);
+        Record r;
+        r.length = int32_t(n);
+        r.attributes = attributes_;
+        r.timestamp_delta = timestamp_delta_;
+        r.offset_delta = offset_delta_;
+        r.key = key_;
+        r.value = value_;
+        r.headers = headers_;
+        return r;
+    }
+    // From<Record> for Builder, record.rs:316-327: the stored length is dropped
+    static Builder from(const Record &r) {
+        Builder b;
+        b.attributes_ = r.attributes;
+        b.timestamp_delta_ = r.timestamp_delta;
+        b.offset_delta_ = r.offset_delta;
+        b.key_ = r.key;
+        b.value_ = r.value;
+        b.headers_ = r.headers;
+        return b;
+    }
+};
+
+// Sequence<T>, codec.rs:386-522: a u32 count, then the items.  Its ByteSize
+// (codec.rs:482-491) sizes every item as UnsignedVarInt::size_inclusive
+// (varint.rs:536-543): the item's own size behind an UNSIGNED varint of that
+// size.  For record builders the prefix actually written is a zigzag varint
+// (record.rs:345-351), one byte longer where the size s has 64 <= s < 128,
+// 8192 <= s < 16384, 2^20 <= s < 2^21 or 2^27 <= s < 2^28: size_in_bytes is
+// short of the serialised length by one for every such item, as in the reference.
+template <class T>
+struct Sequence {
+    std::vector<T> items;
+    Sequence() = default;
+    Sequence(std::vector<T> v) : items(std::move(v)) {}
+    void extend(std::vector<T> more) {
+        for (T &t : more) items.push_back(std::move(t));
+    }
+    size_t size_in_bytes() const {
+        size_t n = sizeof(uint32_t);
+        for (const T &t : items) {
+            size_t sz = t.size_in_bytes();
+            n += unsigned_varint_size(uint32_t(sz)) + sz;
+        }
+        return n;
+    }
+};
+
 namespace inflated {
 struct Batch;
 struct Frame;
+struct Builder;
 }  // namespace inflated
 
 namespace deflated {
@@ -178,6 +281,10 @@ struct Batch {
     // TryFrom<inflated::Batch> for Batch, deflated.rs:392-409 (uncompressed)
     static Result<Batch> try_from(Codec &codec, const inflated::Batch &batch);
     int64_t max_offset() const { return base_offset + int64_t(last_offset_delta); }  // deflated.rs:412-414
+    // deflated.rs:215-230: attributes bit 4, bit 5; a producer id and a sequence that are both set
+    bool is_transactional() const { return (attributes & 0x10) == 0x10; }
+    bool is_control() const { return (attributes & 0x20) == 0x20; }
+    bool is_idempotent() const { return producer_id != -1 && base_sequence != -1; }
 
     bool operator==(const Batch &o) const {
         return base_offset == o.base_offset && batch_length == o.batch_length &&
@@ -224,6 +331,10 @@ struct Batch {
     // attributes verbatim)
     static Result<Batch> try_from(Codec &codec, deflated::Batch &&batch);
     static Result<Batch> try_from(Codec &codec, const deflated::Batch &batch);
+    // inflated.rs:201-212
+    static inflated::Builder builder();
+    inflated::Builder into_builder() const;
+    int64_t max_offset() const { return base_offset + int64_t(last_offset_delta); }
 
     bool operator==(const Batch &o) const {
         return base_offset == o.base_offset && batch_length == o.batch_length &&
@@ -233,6 +344,51 @@ struct Batch {
                producer_id == o.producer_id && producer_epoch == o.producer_epoch &&
                base_sequence == o.base_sequence && records == o.records;
     }
+};
+
+// inflated::Builder, inflated.rs:296-482.  Defaults as in the reference
+// (inflated.rs:311-329): producer_epoch 0, base_sequence 0, partition_leader_epoch
+// -1, magic 2, both timestamps = now in milliseconds.  Nothing derives
+// last_offset_delta or the records' offset deltas.
+struct Builder {
+    int64_t base_offset = 0;
+    int32_t partition_leader_epoch = -1;
+    int8_t magic = 2;
+    int16_t attributes = 0;
+    int32_t last_offset_delta = 0;
+    int64_t base_timestamp = now_ms();
+    int64_t max_timestamp = base_timestamp;
+    int64_t producer_id = -1;
+    int16_t producer_epoch = 0;
+    int32_t base_sequence = 0;
+    Sequence<record::Builder> records;
+
+    static int64_t now_ms() {
+        return std::chrono::duration_cast<std::chrono::milliseconds>(
+                   std::chrono::system_clock::now().time_since_epoch()).count();
+    }
+    Builder with_base_offset(int64_t v) && { base_offset = v; return std::move(*this); }
+    Builder with_partition_leader_epoch(int32_t v) && { partition_leader_epoch = v; return std::move(*this); }
+    Builder with_magic(int8_t v) && { magic = v; return std::move(*this); }
+    Builder with_attributes(int16_t v) && { attributes = v; return std::move(*this); }
+    Builder with_last_offset_delta(int32_t v) && { last_offset_delta = v; return std::move(*this); }
+    Builder with_base_timestamp(int64_t v) && { base_timestamp = v; return std::move(*this); }
+    Builder with_max_timestamp(int64_t v) && { max_timestamp = v; return std::move(*this); }
+    Builder with_producer_id(int64_t v) && { producer_id = v; return std::move(*this); }
+    Builder with_producer_epoch(int16_t v) && { producer_epoch = v; return std::move(*this); }
+    Builder with_base_sequence(int32_t v) && { base_sequence = v; return std::move(*this); }
+    Builder record(record::Builder r) && { records.extend({std::move(r)}); return std::move(*this); }
+
+    // ByteSize for Builder, inflated.rs:331-346: the 45 bytes of the header that
+    // batch_length counts before record_count, then Sequence::size_in_bytes (which
+    // under-counts, see Sequence)
+    size_t size_in_bytes() const { return 4 + 1 + 4 + 2 + 4 + 8 + 8 + 8 + 2 + 4 + records.size_in_bytes(); }
+
+    // Builder::build, inflated.rs:448-481: batch_length = size_in_bytes(), crc =
+    // CRC-32C over attributes .. records as RecordBatchEncoder writes them
+    // (inflated.rs:429-446), which are the bytes the deflated batch's crc covers
+    // (deflated.rs:318-326): the records go through the device encoder once.
+    Result<Batch> build(Codec &codec) const;
 };
 
 // inflated.rs:29-62
@@ -534,6 +690,51 @@ inline Result<deflated::Batch> deflated::Batch::try_from(Codec &codec, const inf
     auto r = detail::deflate(codec, f);
     if (r.is_err()) return r.error();
     return std::move(r->batches[0]);
+}
+
+inline inflated::Builder inflated::Batch::builder() { return inflated::Builder(); }
+// From<Batch> for Builder, inflated.rs:278-294
+inline inflated::Builder inflated::Batch::into_builder() const {
+    inflated::Builder b;
+    b.base_offset = base_offset;
+    b.partition_leader_epoch = partition_leader_epoch;
+    b.magic = magic;
+    b.attributes = attributes;
+    b.last_offset_delta = last_offset_delta;
+    b.base_timestamp = base_timestamp;
+    b.max_timestamp = max_timestamp;
+    b.producer_id = producer_id;
+    b.producer_epoch = producer_epoch;
+    b.base_sequence = base_sequence;
+    for (const Record &r : records) b.records.items.push_back(record::Builder::from(r));
+    return b;
+}
+inline Result<inflated::Batch> inflated::Builder::build(Codec &codec) const {
+    size_t size = size_in_bytes();
+    if (size > 0x7fffffffu) return Error::from_status(NISSHI_TRY_FROM_INT);
+    inflated::Batch b;
+    b.base_offset = base_offset;
+    b.batch_length = int32_t(size);
+    b.partition_leader_epoch = partition_leader_epoch;
+    b.magic = magic;
+    b.attributes = attributes;
+    b.last_offset_delta = last_offset_delta;
+    b.base_timestamp = base_timestamp;
+    b.max_timestamp = max_timestamp;
+    b.producer_id = producer_id;
+    b.producer_epoch = producer_epoch;
+    b.base_sequence = base_sequence;
+    for (const record::Builder &rb : records.items) {
+        auto r = rb.build();
+        if (r.is_err()) return r.error();
+        b.records.push_back(*r);
+    }
+    // compressed batches are not handled on this path (as everywhere in this library)
+    if (attributes & 7) return Error::from_status((attributes & 7) > 4 ? NISSHI_UNKNOWN_COMPRESSION : NISSHI_COMPRESSED, attributes & 7);
+    auto d = deflated::Batch::try_from(codec, b);
+    if (d.is_err()) return d.error();
+    b.crc = d->crc;
+    return b;
 }
 
 }  // namespace record

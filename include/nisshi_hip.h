@@ -345,6 +345,27 @@ int nisshi_hip_fetch_batches_dev(nisshi_hip_ctx *ctx, const nisshi_fetch_rows *d
                                  int64_t now, const nisshi_columns *d_out, uint32_t batch_cap,
                                  uint32_t *n_batches, void *stream);
 
+/* inflated::Builder::build (nisshi-sans-io/src/record/inflated.rs:448-481) for
+ * batches built from builders and already deflated: fills d_cols->batch_length and
+ * d_cols->crc with what the builder stores in the inflated::Batch it returns, so
+ * that an inflated::Batch rebuilt from these columns equals the reference's.
+ * d_cols: batches whose records come from Record::builder() (every length is the
+ * size of the record's body: the output of nisshi_hip_fetch_batches_dev, or of
+ * nisshi_hip_compact_dev for a rewritten batch); d_out, d_out_off: those batches
+ * as nisshi_hip_encode_dev deflated them.
+ *   crc          = the deflated batch's crc: Builder::crc (inflated.rs:429-446)
+ *                  serialises exactly the bytes that crc covers (deflated.rs:318-326)
+ *   batch_length = Builder::size_in_bytes (inflated.rs:331-346).  It sizes every
+ *                  record's length prefix as an UNSIGNED varint (Sequence::size_in_bytes,
+ *                  record/codec.rs:482-491 through UnsignedVarInt::size_inclusive,
+ *                  primitive/varint.rs:536-543) while the prefix is written zigzag
+ *                  (record.rs:345-351), so it is the wire's batch_length less one for
+ *                  every record whose body size s has 64 <= s < 128, 8192 <= s < 16384,
+ *                  2^20 <= s < 2^21 or 2^27 <= s < 2^28
+ * Batches whose status is not NISSHI_OK are left as they are.  Only enqueues work. */
+int nisshi_hip_builder_fields_dev(nisshi_hip_ctx *ctx, const nisshi_columns *d_cols, uint32_t n_batches,
+                                  const uint8_t *d_out, const uint64_t *d_out_off, void *stream);
+
 /* Host-buffer form: rows and payload in host memory to deflated batches in out
  * (out_off: batch_cap + 1 entries, *n_batches + 1 of them written). */
 int nisshi_hip_fetch(nisshi_hip_ctx *ctx, const nisshi_fetch_rows *rows, uint64_t n_rows,

@@ -25,7 +25,7 @@ EXPORTS = [
     "nisshi_hip_profile_enable", "nisshi_hip_profile_get", "nisshi_hip_profile_name",
     "nisshi_hip_host_alloc", "nisshi_hip_host_free",
     "nisshi_hip_produce_rows_dev", "nisshi_hip_produce_rows", "nisshi_hip_combine_dev",
-    "nisshi_hip_combine", "nisshi_hip_fetch_batches_dev", "nisshi_hip_fetch",
+    "nisshi_hip_combine", "nisshi_hip_fetch_batches_dev", "nisshi_hip_fetch", "nisshi_hip_builder_fields_dev",
     "nisshi_hip_compact_dev", "nisshi_hip_compact",
 ]
 
@@ -141,6 +141,7 @@ def load() -> ctypes.CDLL:
                                                  ctypes.POINTER(C.CColumns), u32, ctypes.POINTER(u32), vp]
     lib.nisshi_hip_fetch.argtypes = [vp, ctypes.POINTER(CFetchRows), u64, vp, u64, ctypes.c_int64, vp, u64,
                                      vp, u32, ctypes.POINTER(u32), ctypes.POINTER(Totals)]
+    lib.nisshi_hip_builder_fields_dev.argtypes = [vp, ctypes.POINTER(C.CColumns), u32, vp, vp, vp]
     lib.nisshi_hip_compact_dev.argtypes = [vp, vp, ctypes.POINTER(C.CColumns), u32, u64, vp,
                                            ctypes.POINTER(C.CColumns), vp, vp, ctypes.POINTER(Totals), vp]
     lib.nisshi_hip_compact.argtypes = [vp, vp, u64, vp, u32, vp, vp, u64, vp, vp, vp, vp, ctypes.POINTER(Totals)]
@@ -386,6 +387,12 @@ class Codec:
             self.ctx, ctypes.byref(d_rows), n_rows, now, ctypes.byref(out.c), batch_cap,
             ctypes.byref(n) if sync else None, self._stream()))
         return out, (n.value if sync else None)
+
+    def builder_fields_dev(self, cols: DeviceColumns, n_batches: int, d_out, d_out_off):
+        """batch_length and crc as inflated::Builder::build stores them, for batches
+        already deflated into d_out (enqueues only)."""
+        self._check(self.lib.nisshi_hip_builder_fields_dev(
+            self.ctx, ctypes.byref(cols.c), n_batches, d_out.data_ptr(), d_out_off.data_ptr(), self._stream()))
 
     def fetch(self, rows: dict, payload: bytes, now: int, batch_cap: int = 64, out_cap: Optional[int] = None):
         """The fetch seam over host buffers: returns (list of deflated batches, totals)."""

@@ -19,8 +19,9 @@ def codec():
     c.close()
 
 
-def fetch_dev(codec, rows, payload, batch_cap=64):
-    """Rows on the GPU -> columns -> encode; returns (status, batches)."""
+def fetch_dev(codec, rows, payload, batch_cap=64, built=None):
+    """Rows on the GPU -> columns -> encode; returns (status, batches).  `built`: a list
+    that receives (batch_length, crc) as inflated::Builder::build stores them."""
     import torch
     n = len(rows["offset"])
     d_rows, keep = codec.fetch_rows_to_device(rows)
@@ -38,6 +39,11 @@ def fetch_dev(codec, rows, payload, batch_cap=64):
     t = codec.encode_dev(cols, nb, d_payload, cols.t["data_off"], out, cap, out_off)
     off = out_off.cpu().numpy()
     raw = out[:t.out_bytes].cpu().numpy().tobytes()
+    if built is not None:
+        codec.builder_fields_dev(cols, nb, out, out_off)
+        bl = cols.t["batch_length"][:nb].cpu().numpy()
+        crc = cols.t["crc"][:nb].cpu().numpy().view(np.uint32)
+        built.extend(zip(bl.tolist(), crc.tolist()))
     return C.OK, [raw[int(off[b]):int(off[b + 1])] for b in range(nb)]
 
 
@@ -128,3 +134,54 @@ def test_produce_then_fetch_round_trip(codec):
     for a, b in zip(orig, back):
         assert (a.key, a.value, a.headers) == (b.key, b.value, b.headers)
         assert a.timestamp_delta - first_ts == b.timestamp_delta
+
+
+def builder_fields_of(batch: bytes):
+    """inflated::Builder::build's batch_length and crc for a deflated batch, by the
+    CPU restatement: inflate it, into_builder(), build()."""
+    st, cols, _, _ = oracle.decode_columns(batch, np.array([0, len(batch)], dtype=np.uint64), True)
+    assert st == C.OK
+    st, bl, crc = oracle.builder_columns(cols, 1, batch, cols["data_off"])
+    assert st == C.OK
+    return int(bl[0]), int(crc[0])
+
+
+@pytest.mark.parametrize("kw", [dict(n=1), dict(n=300, change_every=40, headers=2),
+                                dict(n=5000, change_every=700, gap_rate=0.3)])
+def test_builder_fields(codec, kw):
+    """nisshi_hip_builder_fields_dev after fetch + encode: the inflated::Batch that the
+    reference's Builder::build returns has these batch_length and crc.  Values of
+    55-130 bytes put many records' body sizes in 64..127, where Sequence::size_in_bytes
+    counts the length prefix a byte short (codec.rs:482-491)."""
+    kw = dict(kw)
+    rows, payload = make_rows(kw.pop("n"), seed=9, **kw)
+    built = []
+    st, got = fetch_dev(codec, rows, payload, batch_cap=256, built=built)
+    assert st == C.OK and len(built) == len(got)
+    short = 0
+    for (bl, crc), batch in zip(built, got):
+        assert (bl, crc) == builder_fields_of(batch)
+        wire_bl = int.from_bytes(batch[8:12], "big", signed=True)
+        assert crc == int.from_bytes(batch[17:21], "big") and bl <= wire_bl
+        short += wire_bl - bl
+    assert kw == {} or short > 0
+
+
+def test_builder_fields_golden(codec):
+    """The reference's own case (inflated.rs:533-554): one record with value `def`
+    builds to batch_length 59 and crc 1126819645."""
+    import torch
+    from util import load_vectors
+    raw = bytes(load_vectors()["batch_71"]["bytes"])
+    off = np.array([0, len(raw)], dtype=np.uint64)
+    d_blob, d_off = codec.to_device(np.frombuffer(raw, dtype=np.uint8), off)
+    cols = hip.DeviceColumns(1, 1, 1, codec.device)
+    codec.decode_dev(d_blob, len(raw), d_off, 1, cols)
+    out = torch.zeros(len(raw) + 64, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(2, dtype=torch.int64, device=codec.device)
+    codec.encode_dev(cols, 1, d_blob, cols.t["data_off"], out, len(raw), out_off)
+    cols.t["batch_length"].zero_()
+    cols.t["crc"].zero_()
+    codec.builder_fields_dev(cols, 1, out, out_off)
+    assert int(cols.t["batch_length"][0]) == 59
+    assert int(cols.t["crc"][0].cpu().numpy().view(np.uint32)) == 1126819645
