@@ -1,0 +1,67 @@
+"""The `extern "C"` block of nisshi-hip/src/ffi.rs from include/nisshi_hip.h: one
+declaration a prototype, C types mapped one to one.  tests/test_rust_ffi.py runs
+`declarations()` and compares it with what ffi.rs holds.
+
+    python tools/gen_ffi.py            # prints the block
+"""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TYPES = {"int": "c_int", "void": "c_void", "char": "c_char", "double": "f64",
+         "uint8_t": "u8", "int8_t": "i8", "uint16_t": "u16", "int16_t": "i16",
+         "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64",
+         "nisshi_hip_ctx": "Ctx", "nisshi_columns": "Columns", "nisshi_totals": "Totals",
+         "nisshi_rows": "Rows", "nisshi_fetch_rows": "FetchRows", "nisshi_header_span": "HeaderSpan",
+         "nisshi_record_key": "RecordKey", "nisshi_record_value": "RecordValue"}
+
+
+def header_text():
+    text = open(os.path.join(ROOT, "include", "nisshi_hip.h")).read()
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def rust_type(c: str) -> str:
+    c = c.strip()
+    stars = c.count("*")
+    base = c.replace("*", "").strip()
+    const = base.startswith("const ")
+    if const:
+        base = base[6:].strip()
+    t = TYPES[base]
+    for i in range(stars):   # `const` binds to the pointee; pointers to pointers are mutable
+        t = ("*const " if const and i == 0 else "*mut ") + t
+    return t
+
+
+def prototypes():
+    """[(name, return type, [(parameter, type)])] in header order, as Rust types."""
+    out = []
+    for ret, name, args in re.findall(r"\n\s*((?:const\s+)?\w+\s*\**)\s*(nisshi_\w+)\s*\(([^)]*)\)\s*;", header_text()):
+        params = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            m = re.match(r"(.*?)(\w+)$", a)
+            params.append((m.group(2), rust_type(m.group(1))))
+        out.append((name, rust_type(ret), params))
+    return out
+
+
+def declarations():
+    lines = []
+    for name, ret, params in prototypes():
+        args = ", ".join(f"{p}: {t}" for p, t in params)
+        lines.append(f"    pub fn {name}({args})" + ("" if ret == "c_void" else f" -> {ret}") + ";")
+    return lines
+
+
+def struct_fields(c_name: str):
+    """[(field, Rust type)] of a struct of the header."""
+    text = header_text()
+    body = text[text.index(f"typedef struct {c_name} {{"):text.index(f"}} {c_name};")]
+    return [(f, rust_type(t)) for t, f in re.findall(r"\n\s*((?:const\s+)?\w+\s*\**)\s*(\w+);", body)]
+
+
+if __name__ == "__main__":
+    print("\n".join(declarations()))
