@@ -106,12 +106,20 @@ def main():
     avg_ms = ms / launches
     k_bytes = KERNEL_BYTES.get(name, lambda s: 0)(stats)
     achieved = k_bytes / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM-side bytes per launch of that kernel, from the counter passes of a committed
+    # rocprofv3 profile of this workload (tools/profile_round.sh): reported only while
+    # the kernel sources are the ones that profile was taken of
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
+        from tansu_amd import build as _build
         with open(tpath) as f:
             tj = json.load(f)
-        traffic = tj.get(args.workload, {}).get(name)
+        src = tj.get("_source", {}).get(args.workload)
+        if isinstance(src, dict):
+            traffic_source = dict(src, csrc_sha_now=_build.source_hash())
+            if src.get("csrc_sha") == traffic_source["csrc_sha_now"]:
+                traffic = tj.get(args.workload, {}).get(name)
     result = {
         "metric": "device-resident RecordBatch v2 decode",
         "value": shard.job_rate(n_records, world, args.steps, elapsed),
@@ -148,6 +156,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel_ms": avg_ms,
             "kernel_algorithmic_bytes": k_bytes,
         },

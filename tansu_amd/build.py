@@ -14,6 +14,17 @@ SOURCES = ["nisshi_hip.hip"]
 DEPS = ["nisshi_hip.hip", "encode.inc", "storage.inc", "fetch.inc", "compact.inc", "api.inc", "wire.h", "gf2_crc32c.h"]
 
 
+def source_hash() -> str:
+    """A hash of the kernel sources and the C header: what profiles are taken of.
+    bench.py reports HBM traffic from a committed profile only while this matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, d) for d in sorted(DEPS)] + [os.path.join(ROOT, "include", "nisshi_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True

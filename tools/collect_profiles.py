@@ -1,6 +1,6 @@
-"""Copy the summaries of a scratch/profile_round.sh run from gpurun_out/ into
+"""Copy the summaries of a tools/profile_round.sh run from gpurun_out/ into
 profiles/ (tracked) and refresh profiles/traffic.json, which bench.py reads for
-`roofline.traffic`.  usage: python scratch/collect_profiles.py <tag> <name> [workload]"""
+`roofline.traffic`.  usage: python tools/collect_profiles.py <tag> <name> [workload]"""
 import glob, json, os, re, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
@@ -18,6 +18,7 @@ traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 traffic[workload] = {re.sub(r"^void ", "", re.sub(r"<.*>$", "", k)): v["total"]
                      for k, v in summary["traffic_bytes_per_launch"].items()}
 traffic["_source"] = traffic.get("_source", {})
-traffic["_source"][workload] = f"{name}_summary.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate passes, bytes per launch"
+traffic["_source"][workload] = {"file": f"profiles/{name}_summary.json", "csrc_sha": summary.get("csrc_sha"),
+                                "how": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate passes, bytes per launch"}
 json.dump(traffic, open(tpath, "w"), indent=1)
 print(open(tpath).read())

@@ -1,9 +1,9 @@
-"""Phase counters of the decode walks: build with NISSHI_CXXFLAGS=-DNISSHI_PHASES into scratch/libs/phases.so first.
-python scratch/phases.py <workload> [scale]"""
+"""Phase counters of the decode walks: build with NISSHI_CXXFLAGS=-DNISSHI_PHASES into scratch/libs/phases.so first (scratch/ is not tracked).
+python tools/phases.py <workload> [scale]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from tansu_amd import hip, shard
-hip.LIB_PATH = os.path.abspath(os.path.join(os.path.dirname(__file__), "libs", "phases.so"))
+hip.LIB_PATH = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "scratch", "libs", "phases.so"))
 import torch
 codec = hip.Codec(0)
 scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0

@@ -1,9 +1,12 @@
-"""Summarise one scratch/profile_round.sh run: per-kernel stats of the trace pass
+"""Summarise one tools/profile_round.sh run: per-kernel stats of the trace pass
 and HBM-side traffic per launch from the two counter passes (FETCH_SIZE is in
 KiB and counts 64 B per 128-byte request on gfx950, so it is doubled)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from tansu_amd.build import source_hash
 out = sys.argv[1]
-res = {"kernels": {}, "traffic_bytes_per_launch": {}}
+res = {"workload": sys.argv[2] if len(sys.argv) > 2 else "c2", "csrc_sha": source_hash(), "kernels": {},
+       "traffic_bytes_per_launch": {}}
 for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         res["kernels"][r["Name"].split("(")[0]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
