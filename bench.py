@@ -61,8 +61,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        # the ranks exchange nothing but the barrier around the timed region and the
+        # elapsed time: host-side, over gloo (the data path has no collective)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     codec = hip.Codec(local)

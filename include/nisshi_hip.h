@@ -415,6 +415,44 @@ int nisshi_hip_compact(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_l
                        uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t *removed,
                        int32_t *action, int32_t *status, nisshi_totals *totals);
 
+/* ---- one host frame over several GPUs.  The reference handles a produce
+ * request's batches partition by partition in one loop on one thread
+ * (nisshi-storage/src/service/produce.rs:165-191); batches of different topic
+ * partitions share nothing.  A pool holds one context, one worker thread and
+ * page-locked staging buffers per device; a frame's batch b goes to device
+ * partition[b] mod G (G = the number of devices), the devices decode side by side
+ * (nisshi_hip_decode each: copy in, kernels, copy out), and the columns come back
+ * in input order, as one device decoding the whole frame would leave them: entry
+ * b of every per-batch array is batch b, data_off[b] is an offset in the caller's
+ * blob, rec_base and hdr_base index the caller's record and header arrays (a
+ * device's records are contiguous, devices in ascending order).  No data moves
+ * between devices.  devices: n_devices HIP device ids (NULL: 0 .. n_devices - 1;
+ * an id may repeat, which gives that GPU several contexts).  One call at a time. */
+typedef struct nisshi_hip_pool nisshi_hip_pool;
+int nisshi_hip_pool_create(const int *devices, uint32_t n_devices, nisshi_hip_pool **pool);
+void nisshi_hip_pool_destroy(nisshi_hip_pool *pool);
+uint32_t nisshi_hip_pool_device_count(const nisshi_hip_pool *pool);
+uint32_t nisshi_hip_pool_device_of(const nisshi_hip_pool *pool, uint32_t partition);
+const char *nisshi_hip_pool_last_error(const nisshi_hip_pool *pool);
+/* partition: one id a batch.  totals: those of the frame; device_totals (or NULL):
+ * n_devices entries, each device's own.  Capacities are those of the caller's
+ * columns (header slots with the slack nisshi_hip_decode_dev describes, summed
+ * over the devices). */
+int nisshi_hip_pool_decode(nisshi_hip_pool *pool, const uint8_t *blob, uint64_t blob_len, const uint64_t *batch_off,
+                           uint32_t n_batches, const uint32_t *partition, int by_value, const nisshi_columns *cols,
+                           uint64_t rec_cap, uint64_t hdr_cap, nisshi_totals *totals, nisshi_totals *device_totals);
+/* A pool over decoders other than this library's contexts: device d decodes by
+ * decode(decoder_ctx[d], ...), the arguments those of nisshi_hip_decode; staging
+ * buffers are ordinary host memory.  This is how the scheduling (the partition
+ * map, the order of the shares, the columns put back in input order) is tested on
+ * machines without GPUs, with the tests' CPU checker as the decoder. */
+typedef int (*nisshi_pool_decode_fn)(void *decoder_ctx, const uint8_t *blob, uint64_t blob_len,
+                                     const uint64_t *batch_off, uint32_t n_batches, int by_value,
+                                     const nisshi_columns *cols, uint64_t rec_cap, uint64_t hdr_cap,
+                                     nisshi_totals *totals);
+int nisshi_hip_pool_create_custom(uint32_t n_devices, nisshi_pool_decode_fn decode, void *const *decoder_ctx,
+                                  nisshi_hip_pool **pool);
+
 /* Page-locked host memory for the host-buffer entry points: blobs and columns
  * in buffers from here move over PCIe by DMA at link speed; any other host
  * memory works too, staged by the HIP runtime and several times slower.  (The

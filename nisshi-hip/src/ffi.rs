@@ -126,6 +126,26 @@ pub struct Ctx {
     _private: [u8; 0],
 }
 
+/// `nisshi_hip_pool`: opaque.
+#[repr(C)]
+pub struct Pool {
+    _private: [u8; 0],
+}
+
+/// `nisshi_pool_decode_fn`: the decode of one device of a custom pool, the arguments of `nisshi_hip_decode`.
+pub type PoolDecodeFn = unsafe extern "C" fn(
+    decoder_ctx: *mut c_void,
+    blob: *const u8,
+    blob_len: u64,
+    batch_off: *const u64,
+    n_batches: u32,
+    by_value: c_int,
+    cols: *const Columns,
+    rec_cap: u64,
+    hdr_cap: u64,
+    totals: *mut Totals,
+) -> c_int;
+
 extern "C" {
     pub fn nisshi_hip_ctx_create(device: c_int, ctx: *mut *mut Ctx) -> c_int;
     pub fn nisshi_hip_ctx_destroy(ctx: *mut Ctx);
@@ -149,6 +169,13 @@ extern "C" {
     pub fn nisshi_hip_fetch(ctx: *mut Ctx, rows: *const FetchRows, n_rows: u64, payload: *const u8, payload_len: u64, now: i64, out: *mut u8, out_cap: u64, out_off: *mut u64, batch_cap: u32, n_batches: *mut u32, totals: *mut Totals) -> c_int;
     pub fn nisshi_hip_compact_dev(ctx: *mut Ctx, d_blob: *const u8, d_cols: *const Columns, n_batches: u32, n_slots: u64, d_group: *const u32, d_out: *const Columns, d_removed: *mut u32, d_action: *mut i32, totals: *mut Totals, stream: *mut c_void) -> c_int;
     pub fn nisshi_hip_compact(ctx: *mut Ctx, blob: *const u8, blob_len: u64, batch_off: *const u64, n_batches: u32, group: *const u32, out: *mut u8, out_cap: u64, out_off: *mut u64, removed: *mut u32, action: *mut i32, status: *mut i32, totals: *mut Totals) -> c_int;
+    pub fn nisshi_hip_pool_create(devices: *const c_int, n_devices: u32, pool: *mut *mut Pool) -> c_int;
+    pub fn nisshi_hip_pool_destroy(pool: *mut Pool);
+    pub fn nisshi_hip_pool_device_count(pool: *const Pool) -> u32;
+    pub fn nisshi_hip_pool_device_of(pool: *const Pool, partition: u32) -> u32;
+    pub fn nisshi_hip_pool_last_error(pool: *const Pool) -> *const c_char;
+    pub fn nisshi_hip_pool_decode(pool: *mut Pool, blob: *const u8, blob_len: u64, batch_off: *const u64, n_batches: u32, partition: *const u32, by_value: c_int, cols: *const Columns, rec_cap: u64, hdr_cap: u64, totals: *mut Totals, device_totals: *mut Totals) -> c_int;
+    pub fn nisshi_hip_pool_create_custom(n_devices: u32, decode: PoolDecodeFn, decoder_ctx: *const *mut c_void, pool: *mut *mut Pool) -> c_int;
     pub fn nisshi_hip_host_alloc(ctx: *mut Ctx, bytes: u64, ptr: *mut *mut c_void) -> c_int;
     pub fn nisshi_hip_host_free(ctx: *mut Ctx, ptr: *mut c_void);
     pub fn nisshi_hip_crc32c_dev(ctx: *mut Ctx, d_data: *const u8, len: u64, crc: *mut u32, stream: *mut c_void) -> c_int;

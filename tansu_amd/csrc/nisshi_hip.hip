@@ -1828,3 +1828,4 @@ __global__ void crc_buffer_finish_kernel(const uint8_t *data, uint64_t len, uint
 #include "fetch.inc"
 #include "compact.inc"
 #include "api.inc"
+#include "pool.inc"

@@ -27,7 +27,14 @@ EXPORTS = [
     "nisshi_hip_produce_rows_dev", "nisshi_hip_produce_rows", "nisshi_hip_combine_dev",
     "nisshi_hip_combine", "nisshi_hip_fetch_batches_dev", "nisshi_hip_fetch", "nisshi_hip_builder_fields_dev",
     "nisshi_hip_compact_dev", "nisshi_hip_compact",
+    "nisshi_hip_pool_create", "nisshi_hip_pool_create_custom", "nisshi_hip_pool_destroy",
+    "nisshi_hip_pool_device_count", "nisshi_hip_pool_device_of", "nisshi_hip_pool_last_error",
+    "nisshi_hip_pool_decode",
 ]
+
+POOL_DECODE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                  ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                  ctypes.c_void_p)
 
 
 class Totals(ctypes.Structure):
@@ -145,6 +152,18 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_compact_dev.argtypes = [vp, vp, ctypes.POINTER(C.CColumns), u32, u64, vp,
                                            ctypes.POINTER(C.CColumns), vp, vp, ctypes.POINTER(Totals), vp]
     lib.nisshi_hip_compact.argtypes = [vp, vp, u64, vp, u32, vp, vp, u64, vp, vp, vp, vp, ctypes.POINTER(Totals)]
+    lib.nisshi_hip_pool_create.argtypes = [vp, u32, ctypes.POINTER(vp)]
+    lib.nisshi_hip_pool_create_custom.argtypes = [u32, POOL_DECODE_FN, vp, ctypes.POINTER(vp)]
+    lib.nisshi_hip_pool_destroy.argtypes = [vp]
+    lib.nisshi_hip_pool_destroy.restype = None
+    lib.nisshi_hip_pool_device_count.argtypes = [vp]
+    lib.nisshi_hip_pool_device_count.restype = u32
+    lib.nisshi_hip_pool_device_of.argtypes = [vp, u32]
+    lib.nisshi_hip_pool_device_of.restype = u32
+    lib.nisshi_hip_pool_last_error.argtypes = [vp]
+    lib.nisshi_hip_pool_last_error.restype = ctypes.c_char_p
+    lib.nisshi_hip_pool_decode.argtypes = [vp, vp, u64, vp, u32, vp, i32, ctypes.POINTER(C.CColumns), u64, u64,
+                                           ctypes.POINTER(Totals), vp]
     lib.nisshi_hip_profile_enable.argtypes = [vp, i32]
     lib.nisshi_hip_profile_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     lib.nisshi_hip_profile_name.argtypes = [i32]
@@ -572,3 +591,60 @@ class Codec:
         pieces = [out[int(out_off[g]):int(out_off[g + 1])].tobytes() if status[g] == C.OK else None
                   for g in range(n_g)]
         return pieces, status[:n_g], totals
+
+
+class Pool:
+    """nisshi_hip_pool: a host frame's batches over several devices by partition id,
+    columns back in input order.  `devices`: HIP device ids (an id may repeat), or,
+    with `decoder`, the number of devices of a pool whose devices decode by calling
+    `decoder(index, blob, batch_off, by_value, cols, rec_cap, hdr_cap)` -> (status, totals):
+    the form the CPU tests use."""
+
+    def __init__(self, devices, decoder=None):
+        self.lib = load()
+        pool = ctypes.c_void_p()
+        if decoder is None:
+            ids = (ctypes.c_int * len(devices))(*devices)
+            st = self.lib.nisshi_hip_pool_create(ids, len(devices), ctypes.byref(pool))
+            self.n = len(devices)
+        else:
+            self.n = int(devices)
+            self._cb = POOL_DECODE_FN(decoder)
+            ctxs = (ctypes.c_void_p * self.n)(*[i + 1 for i in range(self.n)])   # the device's index + 1 as its context
+            self._ctxs = ctxs
+            st = self.lib.nisshi_hip_pool_create_custom(self.n, self._cb, ctxs, ctypes.byref(pool))
+        if st:
+            raise NisshiError(st, "pool_create")
+        self.pool = pool
+
+    def close(self):
+        if getattr(self, "pool", None):
+            self.lib.nisshi_hip_pool_destroy(self.pool)
+            self.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_of(self, partition: int) -> int:
+        return self.lib.nisshi_hip_pool_device_of(self.pool, partition)
+
+    def decode(self, blob, batch_off, partition, rec_cap: int, hdr_cap: int, by_value: bool = True):
+        """Returns (cols: dict of numpy arrays in the device layout's fields, totals, per-device totals)."""
+        arr = np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else np.ascontiguousarray(blob)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+        part = np.ascontiguousarray(partition, dtype=np.uint32)
+        n_b = len(off) - 1
+        arrays = C.alloc_device_layout(n_b, rec_cap, hdr_cap)
+        cc = C.as_c(arrays)
+        totals = Totals()
+        per_device = (Totals * self.n)()
+        st = self.lib.nisshi_hip_pool_decode(self.pool, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data,
+                                             n_b, part.ctypes.data if n_b else None, int(by_value), ctypes.byref(cc),
+                                             rec_cap, hdr_cap, ctypes.byref(totals), per_device)
+        if st:
+            raise NisshiError(st, (self.lib.nisshi_hip_pool_last_error(self.pool) or b"").decode())
+        cols = C.trim(C.unpack(arrays), n_b, min(totals.n_records, rec_cap), min(totals.n_headers, hdr_cap))
+        return cols, totals, list(per_device)

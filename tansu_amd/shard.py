@@ -5,7 +5,7 @@ Batches of different topic-partitions are independent (the reference keeps
 nothing across them: nisshi-storage/src/service/produce.rs:165-191 loops over
 partitions), so rank r of N simply works on its own shard.  The only
 communication is the barrier around the timed region and the max-reduce of the
-elapsed time; both go through torch.distributed (RCCL on GPUs, gloo on CPU).
+elapsed time; both go through torch.distributed over gloo, on the host.
 """
 from __future__ import annotations
 
@@ -80,7 +80,7 @@ def run_timed(step: Callable[[], None], steps: int, warmup: int, sync: Callable[
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64)   # a host tensor: the group is gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TYPES = {"int": "c_int", "void": "c_void", "char": "c_char", "double": "f64",
          "uint8_t": "u8", "int8_t": "i8", "uint16_t": "u16", "int16_t": "i16",
          "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64",
-         "nisshi_hip_ctx": "Ctx", "nisshi_columns": "Columns", "nisshi_totals": "Totals",
+         "nisshi_hip_ctx": "Ctx", "nisshi_hip_pool": "Pool", "nisshi_pool_decode_fn": "PoolDecodeFn", "nisshi_columns": "Columns", "nisshi_totals": "Totals",
          "nisshi_rows": "Rows", "nisshi_fetch_rows": "FetchRows", "nisshi_header_span": "HeaderSpan",
          "nisshi_record_key": "RecordKey", "nisshi_record_value": "RecordValue"}
 
@@ -23,15 +23,19 @@ def header_text():
 
 
 def rust_type(c: str) -> str:
-    c = c.strip()
-    stars = c.count("*")
-    base = c.replace("*", "").strip()
-    const = base.startswith("const ")
-    if const:
-        base = base[6:].strip()
-    t = TYPES[base]
-    for i in range(stars):   # `const` binds to the pointee; pointers to pointers are mutable
-        t = ("*const " if const and i == 0 else "*mut ") + t
+    """`const T *`, `T **`, `T *const *` ... as Rust raw pointers: a `const` in front of
+    what a `*` points at makes that level `*const`, anything else `*mut`."""
+    tokens = re.findall(r"\w+|\*", c)
+    const_pointee = tokens[0] == "const"
+    if const_pointee:
+        tokens = tokens[1:]
+    t = TYPES[tokens[0]]
+    i = 1
+    while i < len(tokens):
+        assert tokens[i] == "*", c
+        t = ("*const " if const_pointee else "*mut ") + t
+        const_pointee = i + 1 < len(tokens) and tokens[i + 1] == "const"
+        i += 2 if const_pointee else 1
     return t
 
 
