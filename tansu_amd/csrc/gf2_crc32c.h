@@ -264,10 +264,10 @@ struct RingCfg {
     }
 };
 
-template <int kRows>
+template <int kRows, bool kFold = true>
 struct BatchStream {
     typedef RingCfg<kRows> Cfg;
-    static constexpr int kRingBytes = Cfg::kRingBytes, kAhead = Cfg::kAhead;
+    static constexpr int kRingBytes = Cfg::kRingBytes, kAhead = Cfg::kAhead, kRows_ = kRows;
     // Offsets are relative to `grid`, the 16-byte boundary at or below the first
     // byte: the stream handles at most 4 GiB.
     uint32_t lo, hi;          // the bytes [lo, hi) are the data; lo < 16
@@ -276,6 +276,10 @@ struct BatchStream {
     lds_u32 *ring;
     int lane;
     const uint8_t *lane_ptr;  // this lane's 16 bytes of row 0
+    // kFold false: the rows only pass through the ring for the walk, no CRC is taken
+    // (a batch whose CRC comes from its chunks, a second walk of a batch); rows
+    // nobody reads may then be skipped
+    static constexpr bool fold = kFold;
 
     __device__ __forceinline__ void init(const uint8_t *base, uint64_t lo_, uint64_t hi_,
                                          lds_u32 *ring_, int lane_) {
@@ -319,8 +323,16 @@ struct BatchStream {
         uint32_t slot = Cfg::slot_of(r);
         *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4) = v;
         if (slot == 0 && lane < kRingGuard / 16) *(lds_u128 *)(ring + kRingBytes / 4 + lane * 4) = v;
-        uint32_t nx[4] = {v.x, v.y, v.z, v.w};
-        crc_fold_row(acc, nx, lane);
+        if (fold) {
+            uint32_t nx[4] = {v.x, v.y, v.z, v.w};
+            crc_fold_row(acc, nx, lane);
+        }
+    }
+
+    // Without a CRC to take, rows that lie before everything a round up to row
+    // `target` reads need not be loaded: the ring holds kRows rows.
+    __device__ __forceinline__ void skip_before(uint32_t target) {
+        if (!fold && target > next_row + (uint32_t)kRows_) next_row = target - (uint32_t)kRows_;
     }
 
     // The first and the last row were folded as loaded: take out the bytes that
@@ -328,6 +340,7 @@ struct BatchStream {
     // value 0xFFFFFFFF).  The fold is linear, so this is an XOR into the
     // accumulator, before the next row is folded.
     __device__ __forceinline__ void fix_edge(uint32_t r) {
+        if (!fold) return;
         uint32_t slot = Cfg::slot_of(r);
         u32x4 raw = *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4);
         uint64_t addr = (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
@@ -379,6 +392,7 @@ struct BatchStream {
     __device__ __forceinline__ void pull(uint32_t target) {
         target = uni(target);
         if (target > rows) target = rows;
+        skip_before(target);
 #pragma nounroll
         while (next_row < target) {
             if (next_row >= 1 && next_row + 8 <= target && next_row + 8 < rows) {
@@ -404,6 +418,7 @@ struct BatchStream {
     __device__ __forceinline__ void pull_wide(uint32_t target, u32x4 (&q)[kAhead]) {
         target = uni(target);
         if (target > rows) target = rows;
+        skip_before(target);
 #pragma nounroll
         while (next_row < target) {
             uint32_t n = uni(target - next_row < (uint32_t)kAhead ? target - next_row : (uint32_t)kAhead);
@@ -414,6 +429,7 @@ struct BatchStream {
 
     // the CRC-32C of [lo, hi)
     __device__ __forceinline__ uint32_t finish(const CrcTables *t) {
+        if (!fold) return 0;
         pull(rows);
         if (hi == lo) return 0;
         uint32_t r = crc_row_residue(acc, lane, t);

@@ -32,7 +32,8 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 
 // Internal per-batch flags
 constexpr uint32_t kFlagExact = 1u;   // needs the sequential walk
-constexpr uint32_t kFlagGlobal = 2u;  // needs the walk from global memory, from a resume point
+constexpr uint32_t kFlagMore = 2u;    // more headers than the slots it was expected to need: walked again
+constexpr uint32_t kFlagBig = 4u;     // CRC from its chunks, records by the second pass
 
 struct Work {
     uint32_t *alloc_count;  // record slots the batch gets
@@ -40,23 +41,83 @@ struct Work {
     uint32_t *chunk_base;   // exclusive scan of n_chunks, n + 1 entries
     uint32_t *partial;      // one residue per CRC work item
     uint32_t *flags;
-    uint32_t *resume_k;     // kFlagGlobal: the first record not yet decoded
-    uint32_t *resume_pos;   // and its offset in the record data
+    // Where a batch's records and headers go follows from sums over the batches
+    // before it, in two levels: a batch's place among the kSumBlock batches of its
+    // block (rec_local, hdr_local) and a sum a block (blk_sum: record slots in the
+    // low half, header slots in the high half).  Header slots are those the batch
+    // is expected to need (hdr_pred: the header count of its first record times its
+    // record count); a batch that turns out to need more gets all of its headers
+    // behind the expected ones of all batches, in batch order (hdr_need, blk_need).
+    uint32_t *hdr_pred, *hdr_need, *rec_local, *hdr_local;
+    uint64_t *blk_sum;
+    uint32_t *blk_need;
+    uint32_t *list;         // batches with work left after the streamed walk, in no particular order
     uint64_t *totals;       // [0] record slots [1] header slots [2] failed [3] exact [4] out bytes [5] chunks
+                            // [6] end of the expected header slots [7] entries of `list`
     uint64_t *tile_sum;     // the scans over very many batches: two sums a tile of kScanTile batches
     uint32_t *chunk_done;   // encode: the CRC work item has its residue already (from the copy of a long span)
 };
 
+constexpr uint32_t kSumBlock = 256;       // batches a block of the two-level sums
+constexpr uint32_t kSumDirect = 128;      // up to this many blocks the consumers add the block sums themselves
+
 // ------------------------------------------------------------ batch header
 
+// The header count of a batch's first record (0 when that record does not decode),
+// and with `all` the sum over all its records by the sequential walk (0 when any
+// of them does not decode): what the batch is expected to need of header slots.
+__device__ inline uint32_t expected_headers(const uint8_t *data, uint32_t data_len, uint32_t count, bool all) {
+    Reader rd(data, data_len);
+    uint32_t pos = 0;
+    uint64_t sum = 0;
+    uint32_t first = 0;
+    for (uint32_t k = 0; k < (all ? count : (count ? 1u : 0u)); k++) {
+        RecordFields f;
+        if (read_record_head(rd, pos, f)) return 0;
+        if ((uint64_t)f.hdr_count * 2 > rd.len - pos) return 0;  // a header is at least two bytes
+        if (!all) {
+            first = (uint32_t)f.hdr_count;
+            break;
+        }
+        for (int32_t j = 0; j < f.hdr_count; j++) {
+            uint32_t o;
+            int32_t n;
+            if (rd.octets(pos, o, n) || rd.octets(pos, o, n)) return 0;
+        }
+        sum += (uint32_t)f.hdr_count;
+    }
+    if (all) return (uint32_t)sum;
+    uint64_t expect = (uint64_t)first * count;
+    return expect * 2 <= data_len ? (uint32_t)expect : 0;
+}
+
+// Exclusive scan of one 64-bit value a thread over a workgroup of kSumBlock threads.
+__device__ inline uint64_t block_exclusive_scan64(uint64_t v, uint64_t *lds, uint64_t &total) {
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) lds[wid] = inc;
+    __syncthreads();
+    uint64_t offset = 0, sum = 0;
+    for (int i = 0; i < (int)(kSumBlock >> 6); i++) {
+        uint64_t t = lds[i];
+        if (i < wid) offset += t;
+        sum += t;
+    }
+    total = sum;
+    return offset + inc - v;
+}
+
 // deflated::Batch::try_from(Bytes), deflated.rs:108-213, in the reference's order
-// of checks; then Compression::try_from (lib.rs:1685-1698).
-__global__ void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
-                                    int by_value, nisshi_columns c, Work w) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    // the call's totals start at zero: their first users are the kernels after this one
-    if (b < 8) w.totals[b] = 0;
-    if (b >= n) return;
+// of checks; then Compression::try_from (lib.rs:1685-1698).  One batch of
+// batch_header_kernel; returns its record slots (low half) and the header slots
+// it is expected to need (high half).
+__device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t *batch_off, uint32_t b, int by_value,
+                                            const nisshi_columns &c, const Work &w, uint32_t count_small) {
     const uint8_t *p = blob + batch_off[b];
     uint64_t len = batch_off[b + 1] - batch_off[b];
     int st = NISSHI_OK;
@@ -138,6 +199,35 @@ __global__ void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_o
         if (hi == lo) chunks = 1;
     }
     w.n_chunks[b] = chunks;
+    // header slots: small batches of a call of small batches are counted exactly
+    // (they are walked a lane each, tiny_batch_kernel), the others expected from
+    // their first record
+    uint32_t expect = 0;
+    if (fits && record_count)
+        expect = expected_headers(p + 61, data_len, record_count, count_small && len <= count_small);
+    w.hdr_pred[b] = expect;
+    w.hdr_need[b] = 0;
+    return ((uint64_t)expect << 32) | (fits ? record_count : 0u);
+}
+
+__global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
+                                    int by_value, nisshi_columns c, Work w, uint32_t count_small) {
+    __shared__ uint64_t wave_sums[kSumBlock >> 6];
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    // the call's totals start at zero: their first users are the kernels after this one
+    if (b < 8) w.totals[b] = 0;
+    uint64_t mine = 0;  // record slots in the low half, expected header slots in the high half
+    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small);
+    uint64_t total;
+    uint64_t before = block_exclusive_scan64(mine, wave_sums, total);
+    if (b < n) {
+        w.rec_local[b] = (uint32_t)before;
+        w.hdr_local[b] = (uint32_t)(before >> 32);
+    }
+    if (threadIdx.x == 0) {
+        w.blk_sum[blockIdx.x] = total;
+        w.blk_need[blockIdx.x] = 0;
+    }
 }
 
 // ------------------------------------------------------------ batch-level scans
@@ -165,10 +255,10 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint3
     return offset + inc - v;
 }
 
-// Exclusive scans over batches: record slots and CRC work items together, as the
-// two halves of one 64-bit sum.  A thread takes kScanItems consecutive batches,
-// so a workgroup takes kScanTile in a pass.  Only batches of at least min_chunks
-// chunks have CRC work items (the others get their CRC elsewhere).
+// Exclusive scan over batches of their CRC work items (the batches of at least
+// min_chunks chunks: the others get their CRC from the wave that walks them).  A
+// thread takes kScanItems consecutive batches, so a workgroup takes kScanTile in a
+// pass.
 //
 // One workgroup goes through all the batches pass by pass (kScanAll).  From
 // kScanTiledFrom batches on that is too slow (3 us a pass), and the scan is two
@@ -193,15 +283,10 @@ __device__ inline uint64_t tile_sums_before(const uint64_t *sums, uint32_t count
 }
 
 __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_columns c, Work w,
-                                                            uint32_t min_chunks, const uint64_t *before,
-                                                            uint32_t mode) {
+                                                            uint32_t min_chunks, uint32_t mode) {
     __shared__ uint64_t wave_sum[16];
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // records in the low half, work items in the high half.  A call may decode one
-    // slice of a blob: its record and header slots then go on where the slice
-    // before it ended, whose totals are `before`.
-    uint64_t run = before && mode != kScanSum ? (uint32_t)before[0] : 0;
-    if (threadIdx.x == 0 && blockIdx.x == 0 && mode != kScanSum) w.totals[1] = before ? before[1] : 0;
+    uint64_t run = 0;
     uint32_t first = 0, last = n;
     if (mode != kScanAll) {
         first = blockIdx.x * kScanTile;
@@ -215,21 +300,18 @@ __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_c
         // 16-byte loads: the workspace arrays are padded past n, so whole groups can
         // be read (entries past n are masked); a dword a lane would cost four times
         // the load instructions on the one CU this runs on
-        uint32_t cnt[kScanItems] = {}, chk[kScanItems] = {};
+        uint32_t chk[kScanItems] = {};
         if (b0 < n) {
 #pragma unroll
             for (int i = 0; i < kScanItems; i += 4) {
-                uint4 a = *reinterpret_cast<const uint4 *>(w.alloc_count + b0 + i);
                 uint4 k = *reinterpret_cast<const uint4 *>(w.n_chunks + b0 + i);
-                cnt[i] = a.x, cnt[i + 1] = a.y, cnt[i + 2] = a.z, cnt[i + 3] = a.w;
                 chk[i] = k.x, chk[i + 1] = k.y, chk[i + 2] = k.z, chk[i + 3] = k.w;
             }
         }
 #pragma unroll
         for (int i = 0; i < kScanItems; i++) {
             bool in = b0 + i < n;
-            uint32_t items = in && chk[i] >= min_chunks ? chk[i] : 0;
-            v[i] = ((uint64_t)items << 32) | (in ? cnt[i] : 0u);
+            v[i] = in && chk[i] >= min_chunks ? chk[i] : 0;
             mine += v[i];
         }
         uint64_t inc = mine;
@@ -248,22 +330,11 @@ __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_c
         }
         __syncthreads();
         uint64_t e = run + before + inc - mine;
-        uint32_t rb[kScanItems], cb[kScanItems];
+        uint32_t cb[kScanItems];
 #pragma unroll
         for (int i = 0; i < kScanItems; i++) {
-            rb[i] = (uint32_t)e;
-            cb[i] = (uint32_t)(e >> 32);
+            cb[i] = (uint32_t)e;
             e += v[i];
-        }
-        if (!store) {
-        } else if (b0 + kScanItems <= n && (reinterpret_cast<uintptr_t>(c.rec_base) & 15) == 0) {
-#pragma unroll
-            for (int i = 0; i < kScanItems; i += 4)
-                *reinterpret_cast<uint4 *>(c.rec_base + b0 + i) = make_uint4(rb[i], rb[i + 1], rb[i + 2], rb[i + 3]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < kScanItems; i++)
-                if (b0 + i < n) c.rec_base[b0 + i] = rb[i];
         }
         if (store && b0 < n) {  // chunk_base is a workspace array, padded like the others
 #pragma unroll
@@ -276,9 +347,8 @@ __global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_c
     if (mode == kScanSum) {
         w.tile_sum[blockIdx.x] = run;
     } else if (last == n) {
-        w.chunk_base[n] = (uint32_t)(run >> 32);
-        w.totals[0] = (uint32_t)run;
-        w.totals[5] = run >> 32;
+        w.chunk_base[n] = (uint32_t)run;
+        w.totals[5] = run;
     }
 }
 
@@ -448,293 +518,134 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 // LDS instructions execute in order, so a block of one wave needs no more.
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
-// Header slots are handed out from one cursor in runs, so that a batch's
-// headers sit in a few contiguous pieces and a record's headers are always
-// contiguous; the order of the pieces between batches is not defined.
-constexpr uint32_t kHdrRunMax = 4096;
+// ---- where a batch's records and headers go
+//
+// Slots are the same whatever the order the batches are decoded in: a batch's
+// records start at the sum of the record slots of the batches before it, its
+// headers at the sum of the header slots those batches are expected to need
+// (batch_header_kernel), and a batch that needs more than it was expected to gets
+// all of its headers behind the expected slots of all batches, again in batch
+// order.  So a batch's headers are one run, in record order, and two decodes of a
+// blob give the same columns.
 
-struct HeaderRuns {
-    unsigned long long *cursor;
-    uint64_t cap;
-    uint32_t run_pos, run_end;   // slots in hand (slot numbers fit 32 bits: the columns hold them so)
-    uint32_t total, first_slot;  // of the batch so far
-    uint32_t run_max = kHdrRunMax;  // slots taken ahead at most
+// Sum over the blocks before `blk` of the two-level sums (record slots in the low
+// half, header slots in the high half); every lane of the wave gets it.
+// `prefixed`: block_prefix_kernel has turned the block sums into running sums.
+__device__ __forceinline__ uint64_t blocks_before(const Work &w, uint32_t blk, bool prefixed, int lane) {
+    if (prefixed) return w.blk_sum[blk];
+    uint64_t v = 0;
+    for (uint32_t j = (uint32_t)lane; j < blk; j += 64) v += w.blk_sum[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
 
-    // Slots for one round of `m` records, `left` records of the batch following
-    // it; lane's record has hc headers (0 in lanes without a record).  Returns
-    // false when the header columns are full.  When the round's slots are one
-    // piece, `piece` is its first slot.
-    __device__ __forceinline__ bool take(uint32_t hc, uint32_t m, uint32_t left, int lane,
-                                         uint32_t &slot, uint32_t &piece, bool &one_piece) {
-        // equal header counts in every record (the usual case) need no scan
-        uint32_t hc0 = uni(hc);
-        bool live = (uint32_t)lane < m;
-        uint32_t inc = __all(hc == (live ? hc0 : 0u)) ? (live ? ((uint32_t)lane + 1) * hc0 : m * hc0)
-                                                       : wave_inclusive_scan(hc, lane);
-        uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        // records whose headers fit in the run in hand use it, the rest a new run
-        uint32_t room = run_end - run_pos;
-        bool fits = inc <= room;
-        uint64_t fit_mask = __ballot(fits);
-        uint32_t n_fit = fit_mask == ~0ull ? 64 : (uint32_t)__ffsll((long long)~fit_mask) - 1;
-        uint32_t used_old = n_fit ? (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)n_fit - 1) : 0;
-        uint32_t rest = sum - used_old;
-        uint64_t new_base = 0;
-        uint32_t grab = 0;
-        if (rest) {
-            // take enough for the records still to come at this round's density
-            uint64_t ahead = (uint64_t)sum * left / m;
-            grab = rest + (uint32_t)(ahead < run_max ? ahead : run_max);
-            if (lane == 0) new_base = atomicAdd(cursor, (unsigned long long)grab);
-            new_base = uni64(new_base);
-            if (new_base + grab > cap || new_base + grab > 0xffffffffull) return false;
+// The first record slot and the first expected header slot of batch b.  `before`:
+// the totals of the slice decoded before this one (the slots go on from there), or NULL.
+__device__ __forceinline__ void batch_bases(const Work &w, uint32_t b, bool prefixed, const uint64_t *before, int lane,
+                                            uint32_t &rec_base, uint32_t &hdr_base) {
+    uint64_t sum = blocks_before(w, b / kSumBlock, prefixed, lane);
+    rec_base = uni((uint32_t)sum + w.rec_local[b] + (before ? (uint32_t)before[0] : 0u));
+    hdr_base = uni((uint32_t)(sum >> 32) + w.hdr_local[b] + (before ? (uint32_t)before[1] : 0u));
+}
+
+// The first header slot of a batch whose headers did not fit its expected slots:
+// behind the expected slots of all batches (totals[6]), after the needs of the
+// batches before it.  Read only in kernels after the one that found the needs.
+__device__ __forceinline__ uint32_t extra_base(const Work &w, uint32_t b, int lane) {
+    uint32_t blk = b / kSumBlock;
+    uint32_t v = 0;
+    for (uint32_t j = (uint32_t)lane; j < blk; j += 64) v += w.blk_need[j];
+    for (uint32_t i = blk * kSumBlock + (uint32_t)lane; i < b; i += 64) v += w.hdr_need[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return uni(v + (uint32_t)w.totals[6]);
+}
+
+// Turns the block sums into running sums (one workgroup): from kSumDirect blocks
+// on, and for calls of small batches, whose kernels take a lane a batch.
+__global__ __launch_bounds__(1024) void block_prefix_kernel(uint32_t n_blocks, Work w) {
+    __shared__ uint64_t wave_sums[16];
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t run = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint64_t v = i < n_blocks ? w.blk_sum[i] : 0, inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
         }
-        one_piece = rest == 0 || used_old == 0;
-        piece = rest ? (uint32_t)new_base : run_pos;
-        slot = (fits ? run_pos : (uint32_t)new_base) + inc - hc - (fits ? 0 : used_old);
-        if (rest) {
-            run_pos = (uint32_t)new_base + rest;
-            run_end = (uint32_t)new_base + grab;
-        } else {
-            run_pos += sum;
+        if (lane == 63) wave_sums[wid] = inc;
+        __syncthreads();
+        uint64_t offset = 0, total = 0;
+        for (int q = 0; q < 16; q++) {
+            uint64_t t = wave_sums[q];
+            if (q < wid) offset += t;
+            total += t;
         }
-        if (total == 0)
-            first_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, __ffsll((long long)__ballot(hc > 0)) - 1);
-        total += sum;
+        __syncthreads();
+        if (i < n_blocks) w.blk_sum[i] = run + offset + inc - v;
+        run += total;
+    }
+}
+
+// The header slots of one batch while it is walked.
+struct HeaderSlots {
+    uint32_t first, next, limit;  // the batch's slots are [first, limit); next: the first one not taken
+    uint64_t cap;                 // slots the header columns have
+    uint32_t count;               // headers of the batch so far
+    bool over;                    // more headers than slots: none is stored from here on, the walk only counts
+    bool full;                    // the header columns end before the batch's slots do
+
+    __device__ __forceinline__ void init(uint32_t first_, uint32_t slots, uint64_t cap_) {
+        first = next = first_;
+        limit = first_ + slots;
+        cap = cap_;
+        count = 0;
+        over = full = false;
+    }
+
+    __device__ __forceinline__ bool advance(uint32_t sum) {
+        count += sum;
+        if (over || full) return false;
+        if (sum > limit - next) {
+            over = true;
+            return false;
+        }
+        if ((uint64_t)next + sum > cap) {
+            full = true;
+            return false;
+        }
+        next += sum;
         return true;
     }
 
-    // The same for m records of hc headers each (hc > 0, uniform): when the run in
-    // hand holds them all, which it does but for a few rounds of a batch, the slots
-    // follow from the lane number.
-    __device__ __forceinline__ bool take_uniform(uint32_t hc, uint32_t m, uint32_t left, int lane,
-                                                 uint32_t &slot, uint32_t &piece, bool &one_piece) {
-        uint32_t sum = m * hc;
-        if (sum <= run_end - run_pos) {
-            slot = run_pos + (uint32_t)lane * hc;
-            piece = run_pos;
-            one_piece = true;
-            if (total == 0) first_slot = run_pos;
-            run_pos += sum;
-            total += sum;
-            return true;
-        }
-        return take((uint32_t)lane < m ? hc : 0u, m, left, lane, slot, piece, one_piece);
+    // Slots for a round of m records from lane 0 up; the lane's record has hc
+    // headers (0 in lanes without a record).  `slot`: the lane's first.  False:
+    // the round's headers are not to be stored (over, or full).
+    __device__ __forceinline__ bool take(uint32_t hc, uint32_t m, int lane, uint32_t &slot) {
+        uint32_t hc0 = uni(hc);
+        bool live = (uint32_t)lane < m;
+        // equal header counts in every record (the usual case) need no scan
+        uint32_t inc = __all(hc == (live ? hc0 : 0u)) ? (live ? ((uint32_t)lane + 1) * hc0 : m * hc0)
+                                                       : wave_inclusive_scan(hc, lane);
+        uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        slot = next + inc - hc;
+        return advance(sum);
+    }
+
+    // The same for m records of hc headers each.
+    __device__ __forceinline__ bool take_uniform(uint32_t hc, uint32_t m, int lane, uint32_t &slot) {
+        slot = next + (uint32_t)lane * hc;
+        return advance(m * hc);
     }
 };
 
 // How a wave's walk of a batch ended.
 constexpr int kWalkDone = 0;
 constexpr int kWalkExact = 1;   // a record that does not decode, or whose length disagrees: exact_walk
-constexpr int kWalkGlobal = 2;  // records too large for the LDS ring: walk_global
 constexpr int kWalkChain = 3;   // records whose sizes or shapes change from one to the next: walk_chain
-
-// ---- the walk from global memory
-//
-// One workgroup of kWalkWaves waves per batch.  Record starts are found up to
-// 64 * kWalkWaves at a time by speculation: thread i assumes that the i-th next
-// record starts i * S bytes on, S being the size of the record before, and
-// decodes the length varint there.  Threads up to and including the first one
-// whose size differs from S did start on a record, and the walk resumes after
-// that thread's record: a wave's records count only when every wave before it
-// found all 64 of its guesses right, which the waves tell each other through LDS.
-// Each resolved record is then decoded by its thread and must end where its
-// length said.  This is the walk for batches the streamed walk leaves: large
-// batches, records too large for its ring, or of a shape it cannot express.
-// Starts at record k0, byte pos0 of the record data.  Every thread of the
-// workgroup calls it, with the same arguments; all return the same value.
-constexpr int kWalkWaves = 4;      // the usual workgroup
-constexpr int kWalkWavesWide = 8;  // where the call has few batches, so that idle workgroups of 512 threads are few too
-
-struct WalkShare {            // one wave's word to the others, two rounds' worth
-    uint32_t taken[2];        // records of the wave that count if the waves before it were full
-    uint32_t full[2];         // all 64 guesses were records of size S
-    uint32_t next_pos[2];     // where the walk goes on after the wave's last record
-    uint32_t next_size[2];    // and that record's size
-    uint32_t bad[2];          // the first guess of the round is no record
-    // found while the records are decoded, read only after the round's second meeting point
-    uint32_t wrong[2];        // a record did not decode, or did not end where its length said
-    uint32_t full_cap[2];     // the header columns are full
-};
-
-template <int kW>
-__device__ __forceinline__ int walk_global(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
-                                           HeaderRuns &runs, uint32_t &first_rec, uint32_t k0, uint32_t pos0,
-                                           int lane, int wave, WalkShare *share) {
-    uint32_t count = uni(c.record_count[b]);
-    uint64_t rbase = uni(c.rec_base[b]);
-    Reader rd(blob + uni64(c.data_off[b]), uni(c.data_len[b]));
-    uint32_t pos = pos0;
-    uint32_t S = count > k0 ? (rd.len - pos0) / (count - k0) : 0;
-    uint32_t tid = (uint32_t)wave * kWave + (uint32_t)lane;
-    constexpr uint32_t kWide = kWave * kW;
-    int outcome = kWalkDone;
-    uint32_t round = 0;
-    for (uint32_t k = k0; k < count && outcome == kWalkDone; round++) {
-        uint32_t par = round & 1;
-        uint32_t m = count - k < kWide ? count - k : kWide;
-        // Touch where the round after this one will look, so that its lines are on
-        // their way from HBM while this round is parsed.
-        uint32_t touched = 0;
-        {
-            uint64_t ahead = (uint64_t)pos + (uint64_t)(m + tid) * S;
-            typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
-            if (ahead + 4 <= rd.len)
-                touched = *(gbl_u32 *)((reinterpret_cast<uintptr_t>(rd.data) + ahead) & ~uintptr_t(3));
-        }
-        // ---- where the records start
-        uint64_t guess64 = (uint64_t)pos + (uint64_t)tid * S;
-        bool in = tid < m && guess64 < rd.len;
-        uint32_t guess = in ? (uint32_t)guess64 : 0;
-        int32_t len = 0;
-        uint32_t used = 0;
-        bool ok = in && fast_varint(rd.get64(guess), used, len);
-        // the whole record lies inside the data (this also catches a varint cut short)
-        ok = ok && len >= 0 && (uint64_t)guess + used + (uint32_t)len <= rd.len;
-        uint32_t size = ok ? used + (uint32_t)len : 0;
-        uint64_t okmask = __ballot(ok);
-        uint64_t same = __ballot(ok && size == S);
-        uint32_t good = ~same ? (uint32_t)__ffsll((long long)~same) - 1 : 64;
-        uint32_t v = good;  // lanes below `good` are records of size S
-        if (good < 64 && ((okmask >> good) & 1)) v = good + 1;
-        uint32_t mine = m > (uint32_t)wave * kWave ? m - (uint32_t)wave * kWave : 0;  // the wave's share of m
-        if (mine > (uint32_t)kWave) mine = kWave;
-        if (v > mine) v = mine;
-        v = uni(v);
-        if (lane == 0) {
-            share[wave].taken[par] = v;
-            share[wave].full[par] = same == ~0ull ? 1 : 0;
-            share[wave].next_size[par] = v ? (uint32_t)__builtin_amdgcn_readlane((int)size, (int)(v ? v - 1 : 0)) : 0;
-            share[wave].next_pos[par] = v ? (uint32_t)__builtin_amdgcn_readlane((int)guess, (int)(v ? v - 1 : 0)) +
-                                                (uint32_t)__builtin_amdgcn_readlane((int)size, (int)(v ? v - 1 : 0))
-                                          : 0;
-            share[wave].bad[par] = wave == 0 && !(okmask & 1) ? 1 : 0;
-            share[wave].wrong[par] = 0;
-            share[wave].full_cap[par] = 0;
-        }
-        __syncthreads();
-        // ---- which waves' records count: all up to the first that is not full
-        uint32_t taken_before = 0, n_taken = 0, my_taken = 0;
-        bool open = true;
-        uint32_t new_pos = pos, new_S = S;
-#pragma unroll
-        for (int q = 0; q < kW; q++) {
-            uint32_t tq = share[q].taken[par];
-            bool counts = open && tq > 0;
-            if (q == wave) my_taken = counts ? tq : 0, taken_before = n_taken;
-            if (counts) {
-                n_taken += tq;
-                new_pos = share[q].next_pos[par];
-                new_S = share[q].next_size[par];
-            }
-            open = open && share[q].full[par] && tq == (uint32_t)kWave;
-        }
-        if (share[0].bad[par]) {
-            outcome = kWalkExact;  // the same in every wave
-            break;
-        }
-        // ---- one thread per record: the fields after the length
-        bool live = (uint32_t)lane < my_taken;
-        uint32_t end = guess + size;
-        uint32_t p = guess + used;
-        ok = live;
-        RecordFields f;
-        f.length = len;
-        f.attributes = 0;
-        f.timestamp_delta = 0;
-        f.offset_delta = 0;
-        f.key_off = f.val_off = 0;
-        f.key_len = f.val_len = -1;
-        f.hdr_count = 0;
-        if (live) {
-            uint32_t n;
-            uint64_t w0 = rd.get64(p);  // attributes, then the timestamp delta
-            f.attributes = (uint32_t)w0 & 0xffu;
-            if (fast_varlong((uint32_t)(w0 >> 8), n, f.timestamp_delta)) {
-                p += 1 + n;
-            } else {
-                p += 1;
-                ok = rd.varlong(p, f.timestamp_delta) == NISSHI_OK;
-            }
-            ok = fast_varint(rd.get64(p), n, f.offset_delta) && ok;
-            p += n;
-            ok = fast_varint(rd.get64(p), n, f.key_len) && ok;
-            p += n;
-            f.key_off = p;
-            ok = ok && f.key_len >= -1 && p <= end && (uint32_t)(f.key_len < 0 ? 0 : f.key_len) <= end - p;
-            p += ok && f.key_len > 0 ? (uint32_t)f.key_len : 0u;
-            ok = fast_varint(rd.get64(p), n, f.val_len) && ok;
-            p += n;
-            f.val_off = p;
-            ok = ok && f.val_len >= -1 && p <= end && (uint32_t)(f.val_len < 0 ? 0 : f.val_len) <= end - p;
-            p += ok && f.val_len > 0 ? (uint32_t)f.val_len : 0u;
-            ok = fast_varint(rd.get64(p), n, f.hdr_count) && ok;
-            p += n;
-            // a header is at least two bytes: a count the record cannot hold is an error
-            ok = ok && f.hdr_count >= 0 && p <= end && (uint32_t)f.hdr_count <= (end - p) / 2;
-        }
-        uint32_t hc = ok ? (uint32_t)f.hdr_count : 0;
-        uint32_t slot = 0;
-        bool no_room = false;
-        if (__any(hc != 0)) {
-            uint32_t piece;
-            bool one_piece;
-            uint32_t had = runs.total;
-            // what the wave may still have to store in this walk: its share of the records to come
-            uint32_t left = (count - k - taken_before - my_taken) / kW;
-            if (!runs.take(hc, my_taken, left, lane, slot, piece, one_piece)) {
-                no_room = true;
-            } else {
-                if (had == 0) first_rec = k + taken_before + (uint32_t)__ffsll((long long)__ballot(hc != 0)) - 1;
-                for (uint32_t j = 0; j < hc && ok; j++) {
-                    uint32_t n, ko, vo;
-                    int32_t kl, vl;
-                    ok = fast_varint(rd.get64(p), n, kl);
-                    p += n;
-                    ko = p;
-                    ok = ok && kl >= -1 && p <= end && (uint32_t)(kl < 0 ? 0 : kl) <= end - p;
-                    p += ok && kl > 0 ? (uint32_t)kl : 0u;
-                    ok = fast_varint(rd.get64(p), n, vl) && ok;
-                    p += n;
-                    vo = p;
-                    ok = ok && vl >= -1 && p <= end && (uint32_t)(vl < 0 ? 0 : vl) <= end - p;
-                    p += ok && vl > 0 ? (uint32_t)vl : 0u;
-                    if (ok) {
-                        store_header(c, slot + j, ko, kl, vo, vl);
-                    }
-                }
-            }
-        }
-        // the fields must end exactly where the length said
-        bool wrong = __any(live && !no_room && (!ok || p != end));
-        if (live && !no_room && !wrong) store_record(c, rbase + k + taken_before, (uint32_t)lane, f, slot);
-        // what went wrong in any wave ends the walk in all of them: told at the next
-        // round's meeting point, or at the one after the loop
-        if (lane == 0) {
-            if (wrong) share[wave].wrong[par] = 1;
-            if (no_room) share[wave].full_cap[par] = 1;
-        }
-        __syncthreads();
-        uint32_t any_bad = 0, any_full = 0;
-#pragma unroll
-        for (int q = 0; q < kW; q++) {
-            any_bad |= share[q].wrong[par];
-            any_full |= share[q].full_cap[par];
-        }
-        if (any_full) {
-            if (tid == 0) c.status[b] = NISSHI_CAPACITY;
-            outcome = kWalkDone;
-            asm volatile("" ::"v"(touched));
-            break;
-        }
-        if (any_bad) outcome = kWalkExact;
-        k += n_taken;
-        pos = new_pos;
-        S = new_S;
-        asm volatile("" ::"v"(touched));  // the touch is waited for here, a round after it was issued
-    }
-    return outcome;
-}
 
 // ---- the streamed walk
 //
@@ -809,7 +720,7 @@ struct RingView {
 // Record::decode (record.rs:254-277) on that one record, by lane 0, which leaves
 // the compares, the header spans and the scalars of the shape in LDS.  The record's
 // length varint is known to be valid.  kWalkExact when the record does not decode
-// or does not end where its length says, kWalkGlobal when the compares cannot
+// or does not end where its length says, kWalkChain when the compares cannot
 // express it (a varint of five bytes or more, too many fields).
 //
 // The fields are walked by one loop: 0 length, 1 timestamp delta (after the
@@ -882,7 +793,7 @@ __device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring,
     for (uint32_t i = noted; i < ((noted + 3) & ~3u) && i < kShapeChecks; i++) tab[i] = u32x4{0, 0, 0, 0};
     int st = kWalkDone;
     // a varint too wide for the fast decode may be valid: the slower walk decides
-    if (wide || hc > kShapeHdrs || noted > kShapeChecks) st = kWalkGlobal;
+    if (wide || hc > kShapeHdrs || noted > kShapeChecks) st = kWalkChain;
     // the fields must end exactly where the length said
     else if (bad || p != size) st = kWalkExact;
     out[0] = u32x4{(noted + 3) & ~3u, n_len, (uint32_t)length, o_od};
@@ -896,14 +807,14 @@ __device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring,
 // i * S bytes on and decodes the length varint there; lanes before the first one
 // whose size differs from S did start on a record), tests those records against
 // the shape in hand, learning the first one's shape when it does not fit, and
-// emits the records that fit.  On kWalkGlobal *k_out and *pos_out say where the
-// slower walk resumes.
-template <int kRows>
-__device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c, HeaderRuns &runs,
-                                             BatchStream<kRows> &stream, lds_u128 *tab, int lane,
+// emits the records that fit.  On kWalkChain *k_out and *pos_out say where the
+// chained walk goes on.
+template <int kRows, bool kFold>
+__device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c, uint32_t rec_base, HeaderSlots &slots,
+                                             BatchStream<kRows, kFold> &stream, lds_u128 *tab, int lane,
                                              uint32_t *k_out, uint32_t *pos_out) {
     uint32_t count = uni(c.record_count[b]);
-    uint64_t rbase = uni(c.rec_base[b]);
+    uint64_t rbase = rec_base;
     uint32_t data_len = uni(c.data_len[b]);
     // the record data's offset in the stream: data_off - (batch start + 21) + stream.lo
     uint32_t bias = 40 + stream.lo;
@@ -921,7 +832,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     // record's start, its three free fields and its header slot; the rest follows
     // from the shape, which changes only after the flush.
     struct {
-        bool any, one_piece;
+        bool any, headers;  // headers: the round's headers have slots
         uint32_t m, r0, piece;
         uint32_t start, attributes, slot;
         int32_t ts, od;
@@ -944,20 +855,13 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             f.hdr_count = (int32_t)shape.hc;
             store_record(c, late.r0, (uint32_t)lane, f, late.slot);
         }
-        if (shape.hc == 0) return;
-        if (late.one_piece) {
-            uint32_t o = (late.slot - late.piece) * 16;
-            for (uint32_t j = 0; j < shape.hc; j++, o += 16) {
-                u32x4 e = htab[j];
-                if (live)
-                    put(reinterpret_cast<u32x4 *>(c.hdr + late.piece), o,
-                        u32x4{late.start + e.x, e.y, late.start + e.z, e.w});
-            }
-        } else {
-            for (uint32_t j = 0; j < shape.hc; j++) {
-                u32x4 e = htab[j];
-                if (live) store_header(c, late.slot + j, late.start + e.x, (int32_t)e.y, late.start + e.z, (int32_t)e.w);
-            }
+        if (shape.hc == 0 || !late.headers) return;
+        // the round's headers are one run of slots from `piece` on
+        uint32_t o = (late.slot - late.piece) * 16;
+        for (uint32_t j = 0; j < shape.hc; j++, o += 16) {
+            u32x4 e = htab[j];
+            if (live)
+                put(reinterpret_cast<u32x4 *>(c.hdr + late.piece), o, u32x4{late.start + e.x, e.y, late.start + e.z, e.w});
         }
     };
     // how many of the first m lanes' records, counted from lane 0, have the shape in hand
@@ -1014,8 +918,8 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         S = uni(S);
         k = uni(k);
         cap = uni(cap);
-        if (S > kReach) {  // records the ring cannot hold
-            st = kWalkGlobal;
+        if (S > kReach) {  // records the ring cannot hold: the chained walk reads them from global memory
+            st = kWalkChain;
             break;
         }
         PHASE(0)
@@ -1122,12 +1026,9 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             late.ts = (int32_t)ts;  // a shape's timestamp delta has at most four bytes
             fast_varint(ring.read64(at + shape.o_od), w_used, late.od);
             late.slot = 0;
-            late.one_piece = true;
-            late.piece = 0;
-            bool full = false;
-            if (shape.hc)
-                full = !runs.take_uniform(shape.hc, m, count - k - m, lane, late.slot, late.piece, late.one_piece);
-            if (full) {
+            late.piece = slots.next;
+            late.headers = shape.hc ? slots.take_uniform(shape.hc, m, lane, late.slot) : false;
+            if (slots.full) {
                 if (lane == 0) c.status[b] = NISSHI_CAPACITY;
                 k = count;  // ends the walk, the batch has its status
             } else {
@@ -1175,9 +1076,10 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
 // to 64 starts, or as many as end inside what the ring holds, go one to a lane;
 // then every lane decodes its record's fields from the ring (Record::decode, any
 // shape: wide varints, any number of headers) and must end where the length said.
+// A record larger than what the ring holds is a round of its own: its fields are
+// read from global memory by one lane, in sequence.
 // Starts at record *k_io, byte *pos_io of the record data and leaves there where it
-// stopped.  kWalkExact: a record does not decode as its length says; kWalkGlobal:
-// the next record is larger than the ring.
+// stopped.  kWalkExact: a record does not decode as its length says.
 
 // The hops of the chained walk over records whose length varint has kBytes bytes
 // (1: records under 64 bytes, 2: under 8 KiB), written by hand: the scalar unit
@@ -1304,12 +1206,13 @@ __device__ __forceinline__ bool ring_varlong(const RingView<kRows> &ring, uint32
     return done;
 }
 
-template <int kRows>
-__device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, HeaderRuns &runs,
-                                          BatchStream<kRows> &stream, int lane, uint32_t *k_io, uint32_t *pos_io) {
+template <int kRows, bool kFold>
+__device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const nisshi_columns &c, uint32_t rec_base,
+                                          HeaderSlots &slots, BatchStream<kRows, kFold> &stream, int lane,
+                                          uint32_t *k_io, uint32_t *pos_io) {
     typedef RingView<kRows> Ring;
     uint32_t count = uni(c.record_count[b]);
-    uint64_t rbase = uni(c.rec_base[b]);
+    uint64_t rbase = rec_base;
     uint32_t data_len = uni(c.data_len[b]);
     uint32_t bias = 40 + stream.lo;  // the record data's offset in the stream
     constexpr uint32_t kRingBytes = RingCfg<kRows>::kRingBytes;
@@ -1401,10 +1304,52 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
             ro = ro >= kRingBytes ? ro - kRingBytes : ro;
         }
         n = uni(n);
-        if (stop) {
-            st = stop == 1 ? kWalkExact : kWalkGlobal;
+        if (stop == 1) {
+            st = kWalkExact;
             __builtin_amdgcn_s_waitcnt(0x0F70);  // the rows asked for are dropped
             break;
+        }
+        if (stop == 2) {
+            // ---- a record larger than the ring's reach, on its own: Record::decode on it
+            // from global memory (every lane the same reads; lane 0 stores).  The rows
+            // between here and the next record still pass through the stream for the CRC.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            Reader rd(blob + uni64(c.data_off[b]), data_len);
+            uint32_t q0 = pos;
+            RecordFields f;
+            int bad = read_record_head(rd, q0, f);
+            uint32_t len_bytes = 0;
+            {
+                uint32_t t = pos;
+                int32_t unused;
+                bad = bad || rd.varint(t, unused);
+                len_bytes = t - pos;
+            }
+            uint32_t end = pos + len_bytes + (uint32_t)f.length;  // inside the data: the hops checked it
+            bad = bad || (uint64_t)(uint32_t)f.hdr_count * 2 > data_len - q0;
+            uint32_t slot = 0;
+            bool keep = false;
+            if (!bad) keep = slots.take(lane == 0 ? (uint32_t)f.hdr_count : 0u, 1, lane, slot);
+            slot = uni(slot);
+            for (int32_t j = 0; !bad && j < f.hdr_count; j++) {
+                uint32_t ko, vo;
+                int32_t kl, vl;
+                bad = rd.octets(q0, ko, kl) || rd.octets(q0, vo, vl);
+                if (!bad && keep && lane == 0) store_header(c, slot + (uint32_t)j, ko, kl, vo, vl);
+            }
+            if (bad || q0 != end) {
+                st = kWalkExact;
+                break;
+            }
+            if (slots.full) {
+                if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+                k = count;
+                break;
+            }
+            if (lane == 0) store_record(c, rbase + k, 0, f, slot);
+            k += 1;
+            pos = end;
+            continue;
         }
         PHASE(3)
         // ---- a lane a record: the fields
@@ -1447,9 +1392,8 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
         bool no_room = false;
         PHASE(4)
         if (__any(hc != 0)) {
-            uint32_t piece;
-            bool one_piece;
-            if (!runs.take(hc, n, count - k - n, lane, slot, piece, one_piece)) {
+            bool keep = slots.take(hc, n, lane, slot);
+            if (slots.full) {
                 no_room = true;
             } else {
                 uint32_t most = 0;
@@ -1480,7 +1424,7 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
                         ok = good;
                         if (good) {
                             o = o1;
-                            store_header(c, slot + j, ko, kl, vo, vl);
+                            if (keep) store_header(c, slot + j, ko, kl, vo, vl);
                         }
                     }
                 }
@@ -1525,10 +1469,84 @@ __device__ __forceinline__ int walk_chain(uint32_t b, const nisshi_columns &c, H
     return st;
 }
 
+// One lane: Record::decode in sequence, exactly as
+// Vec<Record>::try_from(deflated::Batch) does (deflated.rs:431-442).  The first
+// error ends the batch with that status.  kStore false: only the outcome and the
+// header count (what the batch needs of header slots); true: records are stored
+// while the batch has record slots (a batch whose count cannot fit has none and
+// only gets its status), headers from `hdr_first` on, of which it has `hdr_slots`.
+template <bool kStore>
+__device__ __forceinline__ int exact_walk(const uint8_t *blob, uint32_t b, const nisshi_columns &c, const Work &w,
+                                          uint32_t rbase, uint32_t hdr_first, uint32_t hdr_slots, uint64_t hdr_cap,
+                                          uint32_t *hdr_total_out) {
+    uint32_t count = c.record_count[b];
+    uint32_t slots = w.alloc_count[b];
+    Reader rd(blob + c.data_off[b], c.data_len[b]);
+    uint32_t pos = 0, hdr_total = 0;
+    int st = NISSHI_OK;
+    bool short_of_slots = false;
+    for (uint32_t k = 0; k < count && st == NISSHI_OK; k++) {
+        RecordFields f;
+        st = read_record_head(rd, pos, f);
+        if (st) break;
+        // a header is at least two bytes: a count the data cannot hold fails below
+        bool keep = kStore && k < slots && (uint64_t)(uint32_t)f.hdr_count * 2 <= rd.len - pos;
+        if (keep && f.hdr_count > 0) {
+            // headers beyond the batch's slots or the columns' end are not stored; the walk
+            // goes on, since an error further on is the batch's outcome before that is
+            if ((uint64_t)hdr_total + (uint32_t)f.hdr_count > hdr_slots ||
+                (uint64_t)hdr_first + hdr_total + (uint32_t)f.hdr_count > hdr_cap) {
+                short_of_slots = true;
+                keep = false;
+            }
+        }
+        for (int32_t j = 0; j < f.hdr_count; j++) {
+            uint32_t ko, vo;
+            int32_t kl, vl;
+            if ((st = rd.octets(pos, ko, kl))) break;
+            if ((st = rd.octets(pos, vo, vl))) break;
+            if (keep) store_header(c, (uint64_t)hdr_first + hdr_total + (uint32_t)j, ko, kl, vo, vl);
+        }
+        if (st) break;
+        if (kStore && k < slots) store_record(c, (uint64_t)rbase + k, 0, f, hdr_first + hdr_total);
+        hdr_total += (uint32_t)f.hdr_count;
+    }
+    if (st == NISSHI_OK && short_of_slots) st = NISSHI_CAPACITY;
+    *hdr_total_out = st == NISSHI_OK ? hdr_total : 0;
+    return st;
+}
+
+// What the streamed walk leaves of a batch goes on a list for second_pass_kernel.
+__device__ __forceinline__ void list_append(const Work &w, uint32_t b) {
+    unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 7), 1ull);
+    w.list[at] = b;
+}
+
+// A batch whose headers did not fit the slots it was expected to need: it gets
+// `need` slots behind the expected ones (extra_base) and is walked again.
+__device__ __forceinline__ void note_need(const Work &w, uint32_t b, uint32_t need) {
+    w.hdr_need[b] = need;
+    atomicAdd(w.blk_need + b / kSumBlock, need);
+    atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 1), (unsigned long long)need);
+}
+
+// The walk of one batch by one wave: streamed (records of one shape, 64 at a
+// time), chained where the records change from one to the next.
+template <int kRows, bool kFold>
+__device__ __forceinline__ int walk_batch(const uint8_t *blob, uint32_t b, const nisshi_columns &c, uint32_t rec_base,
+                                          HeaderSlots &slots, BatchStream<kRows, kFold> &stream, lds_u128 *shape_tab,
+                                          int lane) {
+    uint32_t k = 0, pos = 0;
+    int st = walk_streamed(b, c, rec_base, slots, stream, shape_tab, lane, &k, &pos);
+    if (st == kWalkChain) st = walk_chain(blob, b, c, rec_base, slots, stream, lane, &k, &pos);
+    return st;
+}
+
 // One wave per batch: CRC-32C of the batch streamed just ahead of the record
 // walk through an LDS ring, so the batch is read from HBM once.  Batches of
-// kBigChunks chunks or more get their CRC from crc_chunks_kernel instead (one
-// wave cannot stream them fast enough) and their records from slow_walk_kernel.
+// kBigChunks chunks or more get their CRC from their chunks (one wave cannot
+// stream them fast enough: the first workgroups of this grid take the chunks) and
+// their records from second_pass_kernel.
 constexpr uint32_t kBigChunks = 8;
 
 template <int kRows, int kWaves, int kPack>
@@ -1536,7 +1554,8 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
                                                           uint64_t hdr_cap, const CrcTables *t,
-                                                          uint32_t chunk_groups) {
+                                                          uint32_t chunk_groups, uint32_t prefixed,
+                                                          const uint64_t *before) {
     // kPack waves a workgroup, each with a batch, a ring and a shape table of its
     // own: no wave waits for another (there is no barrier below)
     __shared__ __attribute__((aligned(16))) uint32_t rings[kPack][RingCfg<kRows>::kRingWords];
@@ -1554,102 +1573,96 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     }
     uint32_t b = (blockIdx.x - chunk_groups) * kPack + wave;
     if (b >= n) return;
+    // where the batch's records and headers go
+    uint32_t rec_base, hdr_base;
+    batch_bases(w, b, prefixed != 0, before, lane, rec_base, hdr_base);
+    uint32_t expect = uni(w.hdr_pred[b]);
+    if (lane == 0) {
+        c.rec_base[b] = rec_base;
+        c.hdr_base[b] = hdr_base;
+        if (b + 1 == n) {  // the last batch: the ends of the record slots and of the expected header slots
+            w.totals[0] = (uint64_t)rec_base + w.alloc_count[b];
+            w.totals[6] = (uint64_t)hdr_base + expect;
+            atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 1), (unsigned long long)hdr_base + expect);
+        }
+    }
     uint32_t chunks = uni(w.n_chunks[b]);
-    if (chunks == 0 || chunks >= kBigChunks) return;
-    bool do_walk = uni(c.status[b]) == NISSHI_OK && !(uni(w.flags[b]) & kFlagExact);
-    if (do_walk && (uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
+    uint32_t flags = uni(w.flags[b]);
+    int status = (int)uni((uint32_t)c.status[b]);
+    if (chunks == 0) {
+        // done already (a small batch of a call of small batches), or no CRC to take: the header failed early
+        if (lane == 0 && status != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+        return;
+    }
+    if (chunks >= kBigChunks) {
+        if (lane == 0) {
+            w.flags[b] = flags | kFlagBig;
+            list_append(w, b);
+        }
+        return;
+    }
+    bool do_walk = status == NISSHI_OK && !(flags & kFlagExact);
+    if (do_walk && (uint64_t)rec_base + uni(c.record_count[b]) > rec_cap) {
         if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+        status = NISSHI_CAPACITY;
         do_walk = false;
     }
-    BatchStream<kRows> stream;
+    BatchStream<kRows, true> stream;
     uint64_t lo = batch_off[b] + 21;
     stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
+    bool exact = status == NISSHI_OK && (flags & kFlagExact);
     if (do_walk) {
-        HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
-        uint32_t k = 0, pos = 0;
-        int st = walk_streamed(b, c, runs, stream, (lds_u128 *)shape_tab, lane, &k, &pos);
-        // records of changing sizes, or of shapes the compares cannot express: hop by hop
-        if (st == kWalkChain || st == kWalkGlobal) st = walk_chain(b, c, runs, stream, lane, &k, &pos);
-        if (lane == 0) {
-            c.hdr_count[b] = runs.total;
-            c.hdr_base[b] = runs.first_slot;
-            if (st == kWalkExact) w.flags[b] |= kFlagExact;
-            if (st == kWalkGlobal) {
-                w.flags[b] |= kFlagGlobal;
-                w.resume_k[b] = k;
-                w.resume_pos[b] = pos;
+        HeaderSlots slots;
+        slots.init(hdr_base, expect, hdr_cap);
+        int st = walk_batch(blob, b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane);
+        if (st == kWalkExact) {
+            exact = true;
+        } else if (lane == 0) {
+            c.hdr_count[b] = slots.count;
+            if (uni((uint32_t)c.status[b]) != NISSHI_OK) {  // the columns ended inside the batch
+                atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+            } else if (slots.over) {
+                note_need(w, b, slots.count);
+                w.flags[b] = flags | kFlagMore;
+                list_append(w, b);
             }
+        }
+    } else if (lane == 0 && status != NISSHI_OK) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+    }
+    if (exact && lane == 0) {
+        // The sequential walk decides: first only the outcome and the header count, so
+        // that the batch's header slots are known before anything is stored behind the
+        // expected ones; the records and headers are stored by second_pass_kernel.
+        uint32_t headers = 0;
+        int st = exact_walk<false>(blob, b, c, w, rec_base, 0, 0, 0, &headers);
+        atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
+        if (st == NISSHI_OK && (uint64_t)rec_base + w.alloc_count[b] > rec_cap) st = NISSHI_CAPACITY;
+        c.status[b] = st;
+        c.hdr_count[b] = headers;
+        if (st != NISSHI_OK) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+        } else {
+            if (headers > expect) note_need(w, b, headers);
+            w.flags[b] = flags | kFlagExact;
+            list_append(w, b);
         }
     }
     uint32_t v = stream.finish(t);
     if (lane == 0) c.crc_computed[b] = v;
 }
 
-// One lane per flagged batch: Record::decode in sequence, exactly as
-// Vec<Record>::try_from(deflated::Batch) does (deflated.rs:431-442).  The first
-// error ends the batch with its status; records are stored only while the batch
-// has slots (a batch whose count cannot fit has none and only gets its status).
-__device__ __forceinline__ void exact_walk(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
-                                        const Work &w, uint64_t rec_cap, uint64_t hdr_cap) {
-    uint32_t count = c.record_count[b];
-    uint32_t slots = w.alloc_count[b];
-    uint32_t rbase = c.rec_base[b];
-    if ((uint64_t)rbase + slots > rec_cap) {
-        c.status[b] = NISSHI_CAPACITY;
-        return;
-    }
-    unsigned long long *hdr_cursor = reinterpret_cast<unsigned long long *>(w.totals + 1);
-    Reader rd(blob + c.data_off[b], c.data_len[b]);
-    uint32_t pos = 0, hdr_total = 0, first_slot = 0;
-    int st = NISSHI_OK;
-    for (uint32_t k = 0; k < count && st == NISSHI_OK; k++) {
-        RecordFields f;
-        st = read_record_head(rd, pos, f);
-        if (st) break;
-        uint64_t slot = 0;
-        bool keep = k < slots && f.hdr_count > 0;
-        if (keep) {
-            // a header is at least two bytes: a count the data cannot hold fails below
-            uint32_t want = (uint32_t)f.hdr_count;
-            if ((uint64_t)want * 2 > rd.len - pos) {
-                keep = false;
-            } else {
-                slot = atomicAdd(hdr_cursor, (unsigned long long)want);
-                if (slot + want > hdr_cap) {
-                    c.status[b] = NISSHI_CAPACITY;
-                    return;
-                }
-                if (hdr_total == 0) first_slot = (uint32_t)slot;
-            }
-        }
-        for (int32_t j = 0; j < f.hdr_count; j++) {
-            uint32_t ko, vo;
-            int32_t kl, vl;
-            if ((st = rd.octets(pos, ko, kl))) break;
-            if ((st = rd.octets(pos, vo, vl))) break;
-            if (keep) {
-                store_header(c, slot + j, ko, kl, vo, vl);
-            }
-        }
-        if (st) break;
-        if (k < slots) store_record(c, (uint64_t)rbase + k, 0, f, (uint32_t)slot);
-        hdr_total += (uint32_t)f.hdr_count;
-    }
-    c.status[b] = st;
-    c.hdr_count[b] = st == NISSHI_OK ? hdr_total : 0;
-    c.hdr_base[b] = first_slot;
-}
-
 // Batches of a few hundred bytes, a lane each: a workgroup a batch spends more on
 // starting than on the batch (a producer that does not linger sends one record a
 // batch).  The CRC bit by bit, the records by the sequential walk (exact_walk:
-// Record::decode in order, the reference's outcomes by construction).  The batch
-// is then taken off the other kernels' hands (no CRC work item, no flag).
+// Record::decode in order, the reference's outcomes by construction); their
+// header slots were counted by batch_header_kernel, and the block sums are running
+// sums by now.  The batch is then taken off the other kernels' hands (no CRC work item).
 constexpr uint32_t kTinyBytes = 1024;
 
 __global__ __launch_bounds__(256) void tiny_batch_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
                                                          nisshi_columns c, Work w, uint64_t rec_cap,
-                                                         uint64_t hdr_cap) {
+                                                         uint64_t hdr_cap, const uint64_t *before) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
     uint64_t at = batch_off[b];
@@ -1666,106 +1679,105 @@ __global__ __launch_bounds__(256) void tiny_batch_kernel(const uint8_t *blob, co
     w.n_chunks[b] = 0;
     uint32_t flags = w.flags[b];
     if (c.status[b] == NISSHI_OK) {
-        exact_walk(blob, b, c, w, rec_cap, hdr_cap);
+        uint64_t sum = w.blk_sum[b / kSumBlock];
+        uint32_t rec_base = (uint32_t)sum + w.rec_local[b] + (before ? (uint32_t)before[0] : 0u);
+        uint32_t hdr_base = (uint32_t)(sum >> 32) + w.hdr_local[b] + (before ? (uint32_t)before[1] : 0u);
+        int st = NISSHI_OK;
+        uint32_t headers = 0;
+        if ((uint64_t)rec_base + w.alloc_count[b] > rec_cap)
+            st = NISSHI_CAPACITY;
+        else
+            st = exact_walk<true>(blob, b, c, w, rec_base, hdr_base, w.hdr_pred[b], hdr_cap, &headers);
+        c.status[b] = st;
+        c.hdr_count[b] = headers;
         if (flags & kFlagExact) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
+        // (a failure is counted by decode_fused_kernel, which looks at every batch)
     }
     w.flags[b] = 0;
 }
 
-// Everything the streamed walk left, one wave per batch: the CRC of batches of
-// kBigChunks chunks or more from their chunks' residues and their record walk
-// from global memory; flagged batches from where the streamed walk stopped; the
-// sequential walk for batches that need the reference's exact outcome; and the
-// batch's share of the totals, its status being final here.
-template <int kW>
-struct SlowShare {
-    WalkShare walk[kW];
-    uint32_t hdr_total[kW], hdr_first_rec[kW], hdr_first_slot[kW];
-};
-
-template <int kW>
-__device__ __forceinline__ void slow_batch(const uint8_t *blob, const uint64_t *batch_off, uint32_t b,
-                                           const nisshi_columns &c, const Work &w, uint64_t rec_cap, uint64_t hdr_cap,
-                                           const CrcTables *t, SlowShare<kW> &sh) {
-    WalkShare *share = sh.walk;
-    uint32_t *hdr_total = sh.hdr_total, *hdr_first_rec = sh.hdr_first_rec, *hdr_first_slot = sh.hdr_first_slot;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool lead = threadIdx.x == 0;
-    uint32_t flags = uni(w.flags[b]);
-    uint32_t chunks = uni(w.n_chunks[b]);
-    bool big = chunks >= kBigChunks;
-    // the usual batch was done by the streamed walk: nothing left
-    if (!big && flags == 0 && uni(c.status[b]) == NISSHI_OK) return;
-    if (big && wave == 0) {
-        uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, chunks, w, t, lane);
-        if (lane == 0) c.crc_computed[b] = v;
-    }
-    bool ok = uni(c.status[b]) == NISSHI_OK;
-    if (ok && !(flags & kFlagExact) && (big || (flags & kFlagGlobal))) {
-        HeaderRuns runs{reinterpret_cast<unsigned long long *>(w.totals + 1), hdr_cap, 0, 0, 0, 0};
-        runs.run_max = kHdrRunMax * 4 / kW;  // the waves together take no more ahead than four would
-        uint32_t k = 0, pos = 0, before = 0, before_slot = 0;
-        bool fits = true;
-        if (flags & kFlagGlobal) {
-            k = uni(w.resume_k[b]);
-            pos = uni(w.resume_pos[b]);
-            before = uni(c.hdr_count[b]);  // the streamed walk's headers come first
-            before_slot = uni(c.hdr_base[b]);
-        } else if ((uint64_t)c.rec_base[b] + c.record_count[b] > rec_cap) {
-            fits = false;
+// What decode_fused_kernel left, a wave a batch of its list: batches of kBigChunks
+// chunks and more (the CRC from the chunks' residues, the records by the walk, the
+// batch passing through the ring without a CRC; `big` = 1 handles these and only
+// these), batches that need the sequential walk's stores, and batches whose
+// headers did not fit their expected slots, walked again with slots behind those
+// of all batches (`big` = 0; in a launch after the one for the big batches, which
+// may find more such batches).
+template <int kRows>
+__global__ __launch_bounds__(64) void second_pass_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
+                                                         nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap,
+                                                         const CrcTables *t, uint32_t big) {
+    __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
+    __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
+    int lane = threadIdx.x & 63;
+    uint32_t entries = (uint32_t)w.totals[7];
+    for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
+        uint32_t b = uni(w.list[e]);
+        uint32_t flags = uni(w.flags[b]);
+        if (((flags & kFlagBig) != 0) != (big != 0)) continue;
+        if (flags & kFlagBig) {
+            uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, uni(w.n_chunks[b]), w, t, lane);
+            if (lane == 0) c.crc_computed[b] = v;
         }
-        if (!fits) {
-            if (lead) c.status[b] = NISSHI_CAPACITY;
-        } else {
-            uint32_t first_rec = 0xffffffffu;
-            int st = walk_global<kW>(blob, b, c, runs, first_rec, k, pos, lane, wave, share);
-            // the batch's headers: every wave took runs of its own
+        uint32_t rec_base = uni(c.rec_base[b]);
+        uint32_t expect = uni(w.hdr_pred[b]), need = uni(w.hdr_need[b]);
+        int status = (int)uni((uint32_t)c.status[b]);
+        if (status != NISSHI_OK) {  // a big batch whose header failed
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+            continue;
+        }
+        uint32_t first = need ? extra_base(w, b, lane) : uni(c.hdr_base[b]);
+        uint32_t have = need ? need : expect;
+        if (flags & kFlagExact) {
             if (lane == 0) {
-                hdr_total[wave] = runs.total;
-                hdr_first_rec[wave] = runs.total ? first_rec : 0xffffffffu;
-                hdr_first_slot[wave] = runs.first_slot;
+                uint32_t headers = 0;
+                // (a big batch whose record count its data cannot hold comes here unwalked)
+                if (flags & kFlagBig) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
+                int st = exact_walk<true>(blob, b, c, w, rec_base, first, have, hdr_cap, &headers);
+                c.hdr_count[b] = headers;
+                c.hdr_base[b] = first;
+                c.status[b] = st;
+                if (st != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
             }
-            __syncthreads();
-            if (lead) {
-                uint32_t total = before, first = 0xffffffffu, slot = before_slot;
-                for (int q = 0; q < kW; q++) {
-                    total += hdr_total[q];
-                    if (!before && hdr_first_rec[q] < first) first = hdr_first_rec[q], slot = hdr_first_slot[q];
-                }
-                c.hdr_count[b] = total;
-                c.hdr_base[b] = slot;
-            }
-            if (st != kWalkDone) flags |= kFlagExact;
+            continue;
         }
-    }
-    if (lead) {
-        if (ok && (flags & kFlagExact) && c.status[b] == NISSHI_OK) exact_walk(blob, b, c, w, rec_cap, hdr_cap);
-        if (c.status[b] != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
-        if (flags & kFlagExact) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
-    }
-}
-
-// A workgroup a batch; or, where nearly every batch has nothing left (blobs of
-// small batches), per_group batches in turn after a look at all of them at once.
-template <bool kGrouped, int kW>
-__global__ __launch_bounds__(kWave * kW) void slow_walk_kernel(const uint8_t *blob, const uint64_t *batch_off,
-                                                                       uint32_t n, nisshi_columns c, Work w,
-                                                                       uint64_t rec_cap, uint64_t hdr_cap,
-                                                                       const CrcTables *t, uint32_t per_group) {
-    __shared__ SlowShare<kW> sh;
-    if (!kGrouped) {
-        if (blockIdx.x < n) slow_batch<kW>(blob, batch_off, blockIdx.x, c, w, rec_cap, hdr_cap, t, sh);
-        return;
-    }
-    uint64_t mine = (uint64_t)blockIdx.x * per_group + threadIdx.x;  // per_group <= the workgroup's threads
-    bool left = threadIdx.x < per_group && mine < n &&
-                (w.n_chunks[mine] >= kBigChunks || w.flags[mine] != 0 || c.status[mine] != NISSHI_OK);
-    if (!__syncthreads_or(left)) return;
-    for (uint32_t i = 0; i < per_group; i++) {
-        uint64_t b = (uint64_t)blockIdx.x * per_group + i;
-        if (b >= n) return;
-        slow_batch<kW>(blob, batch_off, (uint32_t)b, c, w, rec_cap, hdr_cap, t, sh);
-        __syncthreads();  // the next batch reuses the shared state
+        if ((uint64_t)rec_base + uni(c.record_count[b]) > rec_cap) {
+            if (lane == 0) {
+                c.status[b] = NISSHI_CAPACITY;
+                atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+            }
+            continue;
+        }
+        BatchStream<kRows, false> stream;
+        uint64_t lo = batch_off[b] + 21;
+        stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
+        HeaderSlots slots;
+        slots.init(first, have, hdr_cap);
+        int st = walk_batch(blob, b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane);
+        if (lane == 0) {
+            c.hdr_base[b] = first;
+            c.hdr_count[b] = slots.count;
+            if (st == kWalkExact) {
+                // (a big batch only: the others came here because the walk got through)
+                uint32_t headers = 0;
+                int est = exact_walk<false>(blob, b, c, w, rec_base, 0, 0, 0, &headers);
+                atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
+                c.status[b] = est;
+                c.hdr_count[b] = headers;
+                if (est != NISSHI_OK) {
+                    atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+                } else {
+                    if (headers > expect) note_need(w, b, headers);
+                    w.flags[b] = kFlagExact;  // no longer big: the launch after this one stores it
+                }
+            } else if (c.status[b] != NISSHI_OK) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+            } else if (slots.over) {
+                note_need(w, b, slots.count);
+                w.flags[b] = kFlagMore;  // walked once more by the launch after this one
+            }
+        }
+        lds_order();
     }
 }
 

