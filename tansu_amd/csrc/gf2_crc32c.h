@@ -33,7 +33,13 @@ constexpr int kChunkRows = 64;          // rows per CRC work item
 constexpr int kChunkBytes = kRowBytes * kChunkRows;
 
 __host__ __device__ inline uint32_t gf_mulx(uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // three instructions: the low bit spread over the word, the shift, a ^ (spread & P)
+    uint32_t low = (uint32_t)__builtin_amdgcn_sbfe((int)a, 0, 1);
+    return __builtin_amdgcn_bitop3_b32(a >> 1, low, kPolyReflected, 0x78);
+#else
     return (a >> 1) ^ (kPolyReflected & (0u - (a & 1u)));
+#endif
 }
 
 // a * b mod P
@@ -41,7 +47,11 @@ __host__ __device__ inline uint32_t gf_mulmod(uint32_t a, uint32_t b) {
     uint32_t r = 0;
 #pragma unroll 4
     for (int i = 0; i < 32; i++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        r = __builtin_amdgcn_bitop3_b32(r, a, (uint32_t)((int32_t)b >> 31), 0x78);  // r ^ (a & top bit of b, spread)
+#else
         r ^= a & (0u - (b >> 31));
+#endif
         b <<= 1;
         a = gf_mulx(a);
     }
@@ -387,28 +397,20 @@ struct BatchStream {
         if (n && next_row == rows && rows > 1) fix_edge(rows - 1);
     }
 
-    // Rows up to (not including) `target`, one at a time: for the start of a batch
-    // and for what the walk did not ask for in advance.
+    // Rows up to (not including) `target`, for the start of a batch and for what the
+    // walk did not ask for in advance: up to eight at a time, all of them loaded
+    // before the first is taken, so that the start of a batch pays one memory
+    // latency and not one a row.
     __device__ __forceinline__ void pull(uint32_t target) {
         target = uni(target);
         if (target > rows) target = rows;
         skip_before(target);
 #pragma nounroll
         while (next_row < target) {
-            if (next_row >= 1 && next_row + 8 <= target && next_row + 8 < rows) {
-                // eight rows that are not the first or the last: all loaded before the first is taken
-                u32x4 q[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    q[j] = *reinterpret_cast<const u32x4 *>(lane_ptr + (uint64_t)(next_row + j) * kRowBytes);
-#pragma unroll
-                for (int j = 0; j < 8; j++) take(q[j], next_row + j);
-                next_row += 8;
-                continue;
-            }
-            take(fetch(next_row), next_row);
-            if (edge(next_row)) fix_edge(next_row);
-            next_row++;
+            uint32_t n = uni(target - next_row < (uint32_t)kAhead ? target - next_row : (uint32_t)kAhead);
+            u32x4 q[kAhead];
+            load(q, n);
+            take_loaded(q, n);
         }
     }
 

@@ -3,13 +3,17 @@
 // src/record/{deflated,inflated,codec,header}.rs, src/primitive/varint.rs.
 //
 // Decode pipeline (all on one stream):
-//   batch_header_kernel   one lane per batch: the 61-byte header, its checks, the record_data span
-//   scan_batches_kernel   exclusive scans over batches: record slots, CRC work items
-//   crc_chunks_kernel     batches of 512 KiB and more only: one wave per 64 KiB, CRC-32C by sparse folding
+//   batch_header_kernel   one lane per batch: the 61-byte header, its checks, the record_data span;
+//                         a batch's record slots, expected header slots and CRC work items as sums
+//                         within its block of 256 batches and one sum a block
+//   block_prefix_kernel   running sums over the blocks (only for very many batches or tiny ones)
+//   tiny_batch_kernel     calls of batches of a few hundred bytes: one lane per batch
 //   decode_fused_kernel   one wave per batch: CRC-32C streamed just ahead of the record walk;
-//                         record starts by speculation, records matched against a learnt shape
-//   slow_walk_kernel      what the streamed walk left: large batches and unusual records from
-//                         global memory, the sequential walk for exact error outcomes, the totals
+//                         records of one shape 64 at a time, records that change from one to the
+//                         next by a chained walk; the CRC chunks of batches of 512 KiB and more by
+//                         the workgroups at the front of the grid
+//   second_pass_kernel    what the fused kernel listed: large batches, batches whose headers did
+//                         not fit their expected slots, the sequential walk for exact error outcomes
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -23,6 +27,13 @@
 #include "gf2_crc32c.h"
 #include "nisshi_hip.h"
 #include "wire.h"
+
+#ifndef NISSHI_EXACT_INLINE
+#define NISSHI_EXACT_INLINE __forceinline__
+#endif
+#ifndef NISSHI_LARGE_INLINE
+#define NISSHI_LARGE_INLINE __forceinline__
+#endif
 
 namespace nisshi {
 
@@ -38,7 +49,7 @@ constexpr uint32_t kFlagBig = 4u;     // CRC from its chunks, records by the sec
 struct Work {
     uint32_t *alloc_count;  // record slots the batch gets
     uint32_t *n_chunks;     // CRC work items of the batch
-    uint32_t *chunk_base;   // exclusive scan of n_chunks, n + 1 entries
+    uint32_t *chunk_base;   // encode: exclusive scan of n_chunks, n + 1 entries; decode: see blk_chunks
     uint32_t *partial;      // one residue per CRC work item
     uint32_t *flags;
     // Where a batch's records and headers go follows from sums over the batches
@@ -51,6 +62,9 @@ struct Work {
     uint32_t *hdr_pred, *hdr_need, *rec_local, *hdr_local;
     uint64_t *blk_sum;
     uint32_t *blk_need;
+    // the CRC work items of the batches of kBigChunks chunks and more, numbered the same way: chunk_base holds
+    // a batch's first item among those of its block, blk_chunks the items of a block
+    uint32_t *blk_chunks;
     uint32_t *list;         // batches with work left after the streamed walk, in no particular order
     uint64_t *totals;       // [0] record slots [1] header slots [2] failed [3] exact [4] out bytes [5] chunks
                             // [6] end of the expected header slots [7] entries of `list`
@@ -58,6 +72,7 @@ struct Work {
     uint32_t *chunk_done;   // encode: the CRC work item has its residue already (from the copy of a long span)
 };
 
+constexpr uint32_t kBigChunks = 8;        // from this many 64 KiB chunks on a batch's CRC is taken chunk by chunk
 constexpr uint32_t kSumBlock = 256;       // batches a block of the two-level sums
 constexpr uint32_t kSumDirect = 128;      // up to this many blocks the consumers add the block sums themselves
 
@@ -108,6 +123,7 @@ __device__ inline uint64_t block_exclusive_scan64(uint64_t v, uint64_t *lds, uin
         if (i < wid) offset += t;
         sum += t;
     }
+    __syncthreads();  // the sums may be written again
     total = sum;
     return offset + inc - v;
 }
@@ -117,7 +133,8 @@ __device__ inline uint64_t block_exclusive_scan64(uint64_t v, uint64_t *lds, uin
 // batch_header_kernel; returns its record slots (low half) and the header slots
 // it is expected to need (high half).
 __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t *batch_off, uint32_t b, int by_value,
-                                            const nisshi_columns &c, const Work &w, uint32_t count_small) {
+                                            const nisshi_columns &c, const Work &w, uint32_t count_small,
+                                            uint32_t &chunk_items) {
     const uint8_t *p = blob + batch_off[b];
     uint64_t len = batch_off[b + 1] - batch_off[b];
     int st = NISSHI_OK;
@@ -126,7 +143,58 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
     int8_t magic = 0;
     uint32_t crc = 0, record_count = 0, data_len = 0;
     int16_t attributes = 0, producer_epoch = 0;
-    do {
+    if (len >= 61) {
+        // The whole header is there (all but broken batches): its 61 bytes by sixteen
+        // aligned loads that do not wait for one another, shifted into place, then
+        // the reference's checks in its order on what they brought.  (Below, for a
+        // batch cut short, every read follows the check that allows it: a dozen
+        // memory latencies in a row.)
+        uintptr_t at = reinterpret_cast<uintptr_t>(p);
+        uintptr_t a0 = at & ~uintptr_t(3), last = (at + len - 1) & ~uintptr_t(3);
+        typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
+        uint32_t d[17], e[16];
+#pragma unroll
+        for (int i = 0; i < 17; i++) {
+            uintptr_t a = a0 + 4 * i <= last ? a0 + 4 * i : last;
+            d[i] = *(gbl_u32 *)a;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], (uint32_t)(at & 3));
+        auto b32 = [&](int off) -> uint32_t {  // big-endian 32 bits at a constant byte offset
+            uint32_t v = off & 3 ? __builtin_amdgcn_alignbyte(e[(off >> 2) + 1], e[off >> 2], off & 3) : e[off >> 2];
+            return __builtin_bswap32(v);
+        };
+        auto b64 = [&](int off) -> uint64_t { return ((uint64_t)b32(off) << 32) | b32(off + 4); };
+        base_offset = (int64_t)b64(0);
+        batch_length = (int32_t)b32(8);
+        ple = (int32_t)b32(12);
+        magic = (int8_t)(e[4] & 0xff);
+        crc = b32(17);
+        if (batch_length < 0) {
+            st = NISSHI_TRY_FROM_INT;
+        } else if (batch_length < 9 || (uint64_t)batch_length - 9 > len - 21) {
+            st = NISSHI_OVERFLOW;
+        } else {
+            attributes = (int16_t)(b32(21) >> 16);
+            lod = (int32_t)b32(23);
+            base_timestamp = (int64_t)b64(27);
+            max_timestamp = (int64_t)b64(35);
+            producer_id = (int64_t)b64(43);
+            producer_epoch = (int16_t)(b32(51) >> 16);
+            base_sequence = (int32_t)b32(53);
+            record_count = b32(57);
+            int codec = attributes & 7;
+            if (batch_length < 49) {
+                st = NISSHI_OVERFLOW;
+            } else {
+                data_len = (uint32_t)batch_length - 49;
+                if ((uint64_t)data_len > len - 61) st = NISSHI_OVERFLOW;
+                else if (codec > 4) st = NISSHI_UNKNOWN_COMPRESSION;
+                else if (codec != 0) st = NISSHI_COMPRESSED;
+                else if (by_value) attributes = (int16_t)(attributes & 0x78);
+            }
+        }
+    } else do {
         if (len < 8) { st = NISSHI_TRY_GET; break; }
         base_offset = (int64_t)be64(p);
         if (len < 12) { st = NISSHI_TRY_GET; break; }
@@ -199,6 +267,7 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
         if (hi == lo) chunks = 1;
     }
     w.n_chunks[b] = chunks;
+    chunk_items = chunks >= kBigChunks ? chunks : 0;
     // header slots: small batches of a call of small batches are counted exactly
     // (they are walked a lane each, tiny_batch_kernel), the others expected from
     // their first record
@@ -217,16 +286,26 @@ __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *
     // the call's totals start at zero: their first users are the kernels after this one
     if (b < 8) w.totals[b] = 0;
     uint64_t mine = 0;  // record slots in the low half, expected header slots in the high half
-    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small);
+    uint32_t items = 0;  // CRC work items: those of large batches
+    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, items);
     uint64_t total;
     uint64_t before = block_exclusive_scan64(mine, wave_sums, total);
     if (b < n) {
         w.rec_local[b] = (uint32_t)before;
         w.hdr_local[b] = (uint32_t)(before >> 32);
     }
+    // large batches are rare: their items are only scanned where the block has any
+    uint32_t items_total = 0, items_before = 0;
+    if (__syncthreads_or(items != 0)) {
+        uint64_t t64;
+        items_before = (uint32_t)block_exclusive_scan64(items, wave_sums, t64);
+        items_total = (uint32_t)t64;
+    }
+    if (b < n) w.chunk_base[b] = items_before;
     if (threadIdx.x == 0) {
         w.blk_sum[blockIdx.x] = total;
         w.blk_need[blockIdx.x] = 0;
+        w.blk_chunks[blockIdx.x] = items_total;
     }
 }
 
@@ -255,15 +334,12 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint3
     return offset + inc - v;
 }
 
-// Exclusive scan over batches of their CRC work items (the batches of at least
-// min_chunks chunks: the others get their CRC from the wave that walks them).  A
-// thread takes kScanItems consecutive batches, so a workgroup takes kScanTile in a
-// pass.
-//
-// One workgroup goes through all the batches pass by pass (kScanAll).  From
-// kScanTiledFrom batches on that is too slow (3 us a pass), and the scan is two
-// launches of a workgroup a tile: kScanSum leaves the tile's sum in
-// w.tile_sum, kScanApply starts from the sums of the tiles before its own.
+// The scans over batches of the encoder (encode.inc): a thread takes kScanItems
+// consecutive batches, so a workgroup takes kScanTile in a pass.  One workgroup goes
+// through all the batches pass by pass (kScanAll); from kScanTiledFrom batches on
+// that is too slow (3 us a pass), and a scan is two launches of a workgroup a tile:
+// kScanSum leaves the tile's sum in w.tile_sum, kScanApply starts from the sums of
+// the tiles before its own.
 constexpr int kScanItems = 8;
 constexpr uint32_t kScanTile = 1024 * kScanItems;
 constexpr uint32_t kScanTiledFrom = 4 * kScanTile + 1;
@@ -282,80 +358,35 @@ __device__ inline uint64_t tile_sums_before(const uint64_t *sums, uint32_t count
     return total;
 }
 
-__global__ __launch_bounds__(1024) void scan_batches_kernel(uint32_t n, nisshi_columns c, Work w,
-                                                            uint32_t min_chunks, uint32_t mode) {
-    __shared__ uint64_t wave_sum[16];
-    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint64_t run = 0;
-    uint32_t first = 0, last = n;
-    if (mode != kScanAll) {
-        first = blockIdx.x * kScanTile;
-        last = n - first < kScanTile ? n : first + kScanTile;
-        if (mode == kScanApply) run += tile_sums_before(w.tile_sum, blockIdx.x, 1, wave_sum);
+// ------------------------------------------------------------ CRC-32C
+
+// One CRC work item: chunk `chunk` of batch b, by one wave; its residue goes to partial[item].
+__device__ __forceinline__ void crc_chunk_one(uint32_t item, uint32_t b, uint32_t chunk, const uint8_t *blob,
+                                              const uint64_t *batch_off, const int32_t *batch_length,
+                                              uint32_t *crc_out, const Work &w, const CrcTables *t, int lane) {
+    uint32_t chunks = w.n_chunks[b];
+    uint64_t lo = batch_off[b] + 21;
+    uint64_t hi = lo + (uint64_t)batch_length[b] - 9;
+    uint64_t grid = lo & ~uint64_t(15);
+    uint32_t rows = (uint32_t)((hi - grid + kRowBytes - 1) / kRowBytes);
+    uint32_t row0 = chunk * kChunkRows;
+    uint32_t row1 = row0 + kChunkRows < rows ? row0 + kChunkRows : rows;
+    uint64_t first4 = chunk == 0 ? lo : (uint64_t(1) << 62);
+    uint32_t r = crc_rows(blob, grid, lo, hi, first4, row0, row1, lane, t);
+    if (chunk + 1 == chunks) {
+        // the last row was zero padded up to its end: divide the padding out
+        uint64_t pad = grid + (uint64_t)rows * kRowBytes - hi;
+        if (hi == lo) pad = 0;
+        r = gf_mulmod(r, t->inv8[pad]);
     }
-    bool store = mode != kScanSum;
-    for (uint32_t base = first; base < last; base += blockDim.x * kScanItems) {
-        uint32_t b0 = base + threadIdx.x * kScanItems;
-        uint64_t v[kScanItems], mine = 0;
-        // 16-byte loads: the workspace arrays are padded past n, so whole groups can
-        // be read (entries past n are masked); a dword a lane would cost four times
-        // the load instructions on the one CU this runs on
-        uint32_t chk[kScanItems] = {};
-        if (b0 < n) {
-#pragma unroll
-            for (int i = 0; i < kScanItems; i += 4) {
-                uint4 k = *reinterpret_cast<const uint4 *>(w.n_chunks + b0 + i);
-                chk[i] = k.x, chk[i + 1] = k.y, chk[i + 2] = k.z, chk[i + 3] = k.w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kScanItems; i++) {
-            bool in = b0 + i < n;
-            v[i] = in && chk[i] >= min_chunks ? chk[i] : 0;
-            mine += v[i];
-        }
-        uint64_t inc = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint64_t t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        if (lane == 63) wave_sum[wid] = inc;
-        __syncthreads();
-        uint64_t before = 0, total = 0;
-        for (int i = 0; i < (int)(blockDim.x >> 6); i++) {
-            uint64_t s = wave_sum[i];
-            if (i < wid) before += s;
-            total += s;
-        }
-        __syncthreads();
-        uint64_t e = run + before + inc - mine;
-        uint32_t cb[kScanItems];
-#pragma unroll
-        for (int i = 0; i < kScanItems; i++) {
-            cb[i] = (uint32_t)e;
-            e += v[i];
-        }
-        if (store && b0 < n) {  // chunk_base is a workspace array, padded like the others
-#pragma unroll
-            for (int i = 0; i < kScanItems; i += 4)
-                *reinterpret_cast<uint4 *>(w.chunk_base + b0 + i) = make_uint4(cb[i], cb[i + 1], cb[i + 2], cb[i + 3]);
-        }
-        run += total;
-    }
-    if (threadIdx.x != 0) return;
-    if (mode == kScanSum) {
-        w.tile_sum[blockIdx.x] = run;
-    } else if (last == n) {
-        w.chunk_base[n] = (uint32_t)run;
-        w.totals[5] = run;
+    if (lane == 0) {
+        w.partial[item] = r;
+        if (chunks == 1) crc_out[b] = hi == lo ? 0u : ~r;
     }
 }
 
-// ------------------------------------------------------------ CRC-32C
-
 // The CRC work items first, first + stride, ..., one wave each: item -> (batch, chunk)
-// by binary search in the scan.
+// by binary search in the scan over all batches (the encoder's numbering).
 __device__ __forceinline__ void crc_chunk_items(uint32_t first, uint32_t stride, const uint8_t *blob,
                                                 const uint64_t *batch_off, const int32_t *batch_length, uint32_t n,
                                                 uint32_t *crc_out, const Work &w, const CrcTables *t, int lane,
@@ -368,27 +399,76 @@ __device__ __forceinline__ void crc_chunk_items(uint32_t first, uint32_t stride,
             uint32_t mid = (lo_b + hi_b) >> 1;
             if (w.chunk_base[mid] <= item) lo_b = mid; else hi_b = mid;
         }
-        uint32_t b = lo_b;
-        uint32_t chunk = item - w.chunk_base[b];
-        uint32_t chunks = w.n_chunks[b];
-        uint64_t lo = batch_off[b] + 21;
-        uint64_t hi = lo + (uint64_t)batch_length[b] - 9;
-        uint64_t grid = lo & ~uint64_t(15);
-        uint32_t rows = (uint32_t)((hi - grid + kRowBytes - 1) / kRowBytes);
-        uint32_t row0 = chunk * kChunkRows;
-        uint32_t row1 = row0 + kChunkRows < rows ? row0 + kChunkRows : rows;
-        uint64_t first4 = chunk == 0 ? lo : (uint64_t(1) << 62);
-        uint32_t r = crc_rows(blob, grid, lo, hi, first4, row0, row1, lane, t);
-        if (chunk + 1 == chunks) {
-            // the last row was zero padded up to its end: divide the padding out
-            uint64_t pad = grid + (uint64_t)rows * kRowBytes - hi;
-            if (hi == lo) pad = 0;
-            r = gf_mulmod(r, t->inv8[pad]);
+        crc_chunk_one(item, lo_b, item - w.chunk_base[lo_b], blob, batch_off, batch_length, crc_out, w, t, lane);
+    }
+}
+
+// The number of the first CRC work item of (large) batch b in the decoder's
+// two-level numbering; every lane of the wave gets it.
+__device__ __forceinline__ uint32_t chunk_first(const Work &w, uint32_t b, bool prefixed, int lane) {
+    uint32_t blk = b / kSumBlock;
+    uint32_t v = 0;
+    if (prefixed) {
+        v = w.blk_chunks[blk];
+    } else {
+        for (uint32_t j = (uint32_t)lane; j < blk; j += 64) v += w.blk_chunks[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    }
+    return uni(v + w.chunk_base[b]);
+}
+
+// The same items by the decoder's numbering: a block of batches from the block
+// sums (every wave adds them up itself, or finds its way in the running sums),
+// the batch within the block by binary search.  Nothing to do, which is the usual
+// case, costs a wave two loads a lane.
+__device__ __forceinline__ void crc_chunk_items_blocked(uint32_t first, uint32_t stride, const uint8_t *blob,
+                                                        const uint64_t *batch_off, const int32_t *batch_length,
+                                                        uint32_t n, uint32_t *crc_out, const Work &w,
+                                                        const CrcTables *t, int lane, bool prefixed) {
+    uint32_t n_blocks = (n + kSumBlock - 1) / kSumBlock;
+    uint32_t ex0 = 0, ex1 = 0, total;
+    if (prefixed) {
+        total = w.blk_chunks[n_blocks];
+    } else {  // n_blocks <= kSumDirect = 128: lane j holds the sums before blocks j and j + 64
+        uint32_t s0 = (uint32_t)lane < n_blocks ? w.blk_chunks[lane] : 0;
+        uint32_t s1 = (uint32_t)lane + 64 < n_blocks ? w.blk_chunks[lane + 64] : 0;
+        uint32_t i0 = s0, i1 = s1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t u0 = __shfl_up(i0, d, 64), u1 = __shfl_up(i1, d, 64);
+            if (lane >= d) i0 += u0, i1 += u1;
         }
-        if (lane == 0) {
-            w.partial[item] = r;
-            if (chunks == 1) crc_out[b] = hi == lo ? 0u : ~r;
+        i1 += (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+        total = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+        ex0 = i0 - s0;
+        ex1 = i1 - s1;
+    }
+    total = uni(total);
+    for (uint32_t item = first; item < total; item += stride) {
+        uint32_t blk, base;
+        if (prefixed) {
+            uint32_t lo_k = 0, hi_k = n_blocks;  // largest block whose running sum is <= item
+            while (hi_k - lo_k > 1) {
+                uint32_t mid = (lo_k + hi_k) >> 1;
+                if (w.blk_chunks[mid] <= item) lo_k = mid; else hi_k = mid;
+            }
+            blk = lo_k;
+            base = w.blk_chunks[blk];
+        } else {
+            uint64_t m0 = __ballot((uint32_t)lane < n_blocks && ex0 <= item);
+            uint64_t m1 = __ballot((uint32_t)lane + 64 < n_blocks && ex1 <= item);
+            uint32_t top = m1 ? 63u - (uint32_t)__builtin_clzll(m1) : 63u - (uint32_t)__builtin_clzll(m0);
+            blk = m1 ? top + 64 : top;
+            base = (uint32_t)__builtin_amdgcn_readlane((int)(m1 ? ex1 : ex0), (int)top);
         }
+        uint32_t local = item - base;
+        uint32_t lo_b = blk * kSumBlock, hi_b = lo_b + kSumBlock < n ? lo_b + kSumBlock : n;
+        while (hi_b - lo_b > 1) {  // largest batch of the block whose first item is <= local
+            uint32_t mid = (lo_b + hi_b) >> 1;
+            if (w.chunk_base[mid] <= local) lo_b = mid; else hi_b = mid;
+        }
+        crc_chunk_one(item, lo_b, local - w.chunk_base[lo_b], blob, batch_off, batch_length, crc_out, w, t, lane);
     }
 }
 
@@ -432,13 +512,12 @@ __device__ inline uint32_t crc_combine(const uint64_t *batch_off, const int32_t 
 //   v_i <- v_(i-d) * W^d + v_i,  d = 1, 2, 4 .. 32,
 // after which lane 63 holds sum_j R_j * W^(63-j): six multiplications for 64 chunks.
 __device__ inline uint32_t crc_combine_wave(const uint64_t *batch_off, const int32_t *batch_length,
-                                            uint32_t b, uint32_t chunks, const Work &w, const CrcTables *t,
+                                            uint32_t b, uint32_t chunks, const uint32_t *part, const CrcTables *t,
                                             int lane) {
     uint64_t lo = batch_off[b] + 21;
     uint64_t hi = lo + (uint64_t)batch_length[b] - 9;
     uint64_t grid = lo & ~uint64_t(15);
     uint64_t last_bytes = hi - (grid + (uint64_t)(chunks - 1) * kChunkBytes);
-    const uint32_t *part = w.partial + w.chunk_base[b];
     uint32_t m = chunks - 1;  // residues of full chunks, each weighing W against the next
     uint32_t r = 0;
     // 64 at a time from the left; the first group is the short one, padded with zeros on its left
@@ -588,6 +667,30 @@ __global__ __launch_bounds__(1024) void block_prefix_kernel(uint32_t n_blocks, W
         if (i < n_blocks) w.blk_sum[i] = run + offset + inc - v;
         run += total;
     }
+    // the CRC work items of large batches the same way, their total behind the last block
+    __syncthreads();
+    uint32_t crun = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint64_t v = i < n_blocks ? w.blk_chunks[i] : 0, inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_sums[wid] = inc;
+        __syncthreads();
+        uint64_t offset = 0, total = 0;
+        for (int q = 0; q < 16; q++) {
+            uint64_t t = wave_sums[q];
+            if (q < wid) offset += t;
+            total += t;
+        }
+        __syncthreads();
+        if (i < n_blocks) w.blk_chunks[i] = crun + (uint32_t)(offset + inc - v);
+        crun += (uint32_t)total;
+    }
+    if (threadIdx.x == 0) w.blk_chunks[n_blocks] = crun;
 }
 
 // The header slots of one batch while it is walked.
@@ -1184,6 +1287,44 @@ __device__ __forceinline__ void hop_loop(uint32_t ring_at, uint32_t n0, uint32_t
     }
 }
 
+// One record at byte `pos` of batch b's record data, read from global memory:
+// Record::decode (record.rs:254-277) by every lane alike, stored by lane 0 as
+// record `slot_r`.  For records the LDS ring cannot hold.  Returns 0 and the
+// record's end, 1 when it does not decode or does not end where its length says
+// (the sequential walk decides), 2 when the header columns are full.
+__device__ NISSHI_LARGE_INLINE int large_record(const uint8_t *blob, uint32_t b, const nisshi_columns &c,
+                                                      uint64_t slot_r, uint32_t pos, uint32_t data_len,
+                                                      HeaderSlots &slots, int lane, uint32_t *end_out) {
+    Reader rd(blob + uni64(c.data_off[b]), data_len);
+    uint32_t q0 = pos;
+    RecordFields f;
+    int bad = read_record_head(rd, q0, f);
+    uint32_t len_bytes = 0;
+    {
+        uint32_t t = pos;
+        int32_t unused;
+        bad = bad || rd.varint(t, unused);
+        len_bytes = t - pos;
+    }
+    uint32_t end = pos + len_bytes + (uint32_t)f.length;  // inside the data: the hops checked it
+    bad = bad || (uint64_t)(uint32_t)f.hdr_count * 2 > data_len - q0;
+    uint32_t slot = 0;
+    bool keep = false;
+    if (!bad) keep = slots.take(lane == 0 ? (uint32_t)f.hdr_count : 0u, 1, lane, slot);
+    slot = uni(slot);
+    for (int32_t j = 0; !bad && j < f.hdr_count; j++) {
+        uint32_t ko, vo;
+        int32_t kl, vl;
+        bad = rd.octets(q0, ko, kl) || rd.octets(q0, vo, vl);
+        if (!bad && keep && lane == 0) store_header(c, slot + (uint32_t)j, ko, kl, vo, vl);
+    }
+    if (bad || q0 != end) return 1;
+    if (slots.full) return 2;
+    if (lane == 0) store_record(c, slot_r, 0, f, slot);
+    *end_out = end;
+    return 0;
+}
+
 // LongVarInt::decode at ring offset `ro` for deltas of more than four bytes: up
 // to ten.  False on an eleventh byte (Overflow in the reference).
 template <int kRows>
@@ -1310,43 +1451,20 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
             break;
         }
         if (stop == 2) {
-            // ---- a record larger than the ring's reach, on its own: Record::decode on it
-            // from global memory (every lane the same reads; lane 0 stores).  The rows
-            // between here and the next record still pass through the stream for the CRC.
+            // ---- a record larger than the ring's reach, on its own (large_record); the rows
+            // between here and the next record still pass through the stream for the CRC
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            Reader rd(blob + uni64(c.data_off[b]), data_len);
-            uint32_t q0 = pos;
-            RecordFields f;
-            int bad = read_record_head(rd, q0, f);
-            uint32_t len_bytes = 0;
-            {
-                uint32_t t = pos;
-                int32_t unused;
-                bad = bad || rd.varint(t, unused);
-                len_bytes = t - pos;
-            }
-            uint32_t end = pos + len_bytes + (uint32_t)f.length;  // inside the data: the hops checked it
-            bad = bad || (uint64_t)(uint32_t)f.hdr_count * 2 > data_len - q0;
-            uint32_t slot = 0;
-            bool keep = false;
-            if (!bad) keep = slots.take(lane == 0 ? (uint32_t)f.hdr_count : 0u, 1, lane, slot);
-            slot = uni(slot);
-            for (int32_t j = 0; !bad && j < f.hdr_count; j++) {
-                uint32_t ko, vo;
-                int32_t kl, vl;
-                bad = rd.octets(q0, ko, kl) || rd.octets(q0, vo, vl);
-                if (!bad && keep && lane == 0) store_header(c, slot + (uint32_t)j, ko, kl, vo, vl);
-            }
-            if (bad || q0 != end) {
+            uint32_t end = 0;
+            int outcome = large_record(blob, b, c, rbase + k, pos, data_len, slots, lane, &end);
+            if (outcome == 1) {
                 st = kWalkExact;
                 break;
             }
-            if (slots.full) {
+            if (outcome == 2) {
                 if (lane == 0) c.status[b] = NISSHI_CAPACITY;
                 k = count;
                 break;
             }
-            if (lane == 0) store_record(c, rbase + k, 0, f, slot);
             k += 1;
             pos = end;
             continue;
@@ -1476,7 +1594,7 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
 // while the batch has record slots (a batch whose count cannot fit has none and
 // only gets its status), headers from `hdr_first` on, of which it has `hdr_slots`.
 template <bool kStore>
-__device__ __forceinline__ int exact_walk(const uint8_t *blob, uint32_t b, const nisshi_columns &c, const Work &w,
+__device__ NISSHI_EXACT_INLINE int exact_walk(const uint8_t *blob, uint32_t b, const nisshi_columns &c, const Work &w,
                                           uint32_t rbase, uint32_t hdr_first, uint32_t hdr_slots, uint64_t hdr_cap,
                                           uint32_t *hdr_total_out) {
     uint32_t count = c.record_count[b];
@@ -1547,8 +1665,6 @@ __device__ __forceinline__ int walk_batch(const uint8_t *blob, uint32_t b, const
 // kBigChunks chunks or more get their CRC from their chunks (one wave cannot
 // stream them fast enough: the first workgroups of this grid take the chunks) and
 // their records from second_pass_kernel.
-constexpr uint32_t kBigChunks = 8;
-
 template <int kRows, int kWaves, int kPack>
 __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
                                                           const uint64_t *batch_off, uint32_t n,
@@ -1567,15 +1683,47 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     // kBigChunks chunks and more (none, most of the time): in this grid rather than
     // in a launch of their own, and ahead of the batches so that they start first.
     if (blockIdx.x < chunk_groups) {
-        crc_chunk_items(blockIdx.x * kPack + wave, chunk_groups * kPack, blob, batch_off, c.batch_length, n,
-                        c.crc_computed, w, t, lane);
+        crc_chunk_items_blocked(blockIdx.x * kPack + wave, chunk_groups * kPack, blob, batch_off, c.batch_length, n,
+                                c.crc_computed, w, t, lane, prefixed != 0);
         return;
     }
     uint32_t b = (blockIdx.x - chunk_groups) * kPack + wave;
     if (b >= n) return;
+#ifdef NISSHI_PHASES
+    uint64_t tl[6];
+    uint64_t wall0 = wall_clock64();
+    tl[0] = __builtin_readcyclecounter();
+#endif
+    uint32_t chunks = uni(w.n_chunks[b]);
+    uint32_t flags = uni(w.flags[b]);
+    int status = (int)uni((uint32_t)c.status[b]);
+    // The batch's first rows are asked for before anything else is worked out: where
+    // its records and headers go takes a few trips to the L2, and the rows come from
+    // further away.
+#ifdef NISSHI_DIAG_NOFOLD
+    BatchStream<kRows, false> stream;
+#else
+    BatchStream<kRows, true> stream;
+#endif
+    constexpr int kAhead = RingCfg<kRows>::kAhead;
+    u32x4 first_rows[kAhead];
+    uint32_t n_first = 0;
+    bool streamed = chunks != 0 && chunks < kBigChunks;
+#ifdef NISSHI_DIAG_NOSTREAM  // diagnostic builds only: what the kernel costs without parts of its work
+    streamed = false;
+#endif
+    if (streamed) {
+        uint64_t lo = batch_off[b] + 21;
+        stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
+        n_first = stream.rows < (uint32_t)kAhead ? stream.rows : (uint32_t)kAhead;
+        stream.load(first_rows, n_first);
+    }
     // where the batch's records and headers go
     uint32_t rec_base, hdr_base;
     batch_bases(w, b, prefixed != 0, before, lane, rec_base, hdr_base);
+#ifdef NISSHI_PHASES
+    tl[1] = __builtin_readcyclecounter();
+#endif
     uint32_t expect = uni(w.hdr_pred[b]);
     if (lane == 0) {
         c.rec_base[b] = rec_base;
@@ -1586,9 +1734,6 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
             atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 1), (unsigned long long)hdr_base + expect);
         }
     }
-    uint32_t chunks = uni(w.n_chunks[b]);
-    uint32_t flags = uni(w.flags[b]);
-    int status = (int)uni((uint32_t)c.status[b]);
     if (chunks == 0) {
         // done already (a small batch of a call of small batches), or no CRC to take: the header failed early
         if (lane == 0 && status != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
@@ -1601,20 +1746,30 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
         }
         return;
     }
+#ifdef NISSHI_DIAG_NOSTREAM
+    return;
+#endif
     bool do_walk = status == NISSHI_OK && !(flags & kFlagExact);
     if (do_walk && (uint64_t)rec_base + uni(c.record_count[b]) > rec_cap) {
         if (lane == 0) c.status[b] = NISSHI_CAPACITY;
         status = NISSHI_CAPACITY;
         do_walk = false;
     }
-    BatchStream<kRows, true> stream;
-    uint64_t lo = batch_off[b] + 21;
-    stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
+#ifdef NISSHI_DIAG_NOWALK
+    do_walk = false;
+#endif
+    stream.take_loaded(first_rows, n_first);
     bool exact = status == NISSHI_OK && (flags & kFlagExact);
+#ifdef NISSHI_PHASES
+    tl[2] = __builtin_readcyclecounter();
+#endif
     if (do_walk) {
         HeaderSlots slots;
         slots.init(hdr_base, expect, hdr_cap);
         int st = walk_batch(blob, b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane);
+#ifdef NISSHI_PHASES
+        tl[3] = __builtin_readcyclecounter();
+#endif
         if (st == kWalkExact) {
             exact = true;
         } else if (lane == 0) {
@@ -1650,6 +1805,12 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     }
     uint32_t v = stream.finish(t);
     if (lane == 0) c.crc_computed[b] = v;
+#ifdef NISSHI_PHASES
+    tl[4] = __builtin_readcyclecounter();
+    if (lane == 0 && (b % 1024) == 7)
+        printf("fused b=%u wall=%lu..%lu bases=%lu init=%lu walk=%lu finish=%lu\n", b, wall0, wall_clock64(), tl[1] - tl[0],
+               tl[2] - tl[1], tl[3] - tl[2], tl[4] - tl[3]);
+#endif
 }
 
 // Batches of a few hundred bytes, a lane each: a workgroup a batch spends more on
@@ -1706,7 +1867,7 @@ __global__ __launch_bounds__(256) void tiny_batch_kernel(const uint8_t *blob, co
 template <int kRows>
 __global__ __launch_bounds__(64) void second_pass_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
                                                          nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap,
-                                                         const CrcTables *t, uint32_t big) {
+                                                         const CrcTables *t, uint32_t big, uint32_t prefixed) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
     __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
     int lane = threadIdx.x & 63;
@@ -1716,7 +1877,8 @@ __global__ __launch_bounds__(64) void second_pass_kernel(const uint8_t *blob, co
         uint32_t flags = uni(w.flags[b]);
         if (((flags & kFlagBig) != 0) != (big != 0)) continue;
         if (flags & kFlagBig) {
-            uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, uni(w.n_chunks[b]), w, t, lane);
+            const uint32_t *part = w.partial + chunk_first(w, b, prefixed != 0, lane);
+            uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, uni(w.n_chunks[b]), part, t, lane);
             if (lane == 0) c.crc_computed[b] = v;
         }
         uint32_t rec_base = uni(c.rec_base[b]);
