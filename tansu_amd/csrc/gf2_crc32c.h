@@ -282,6 +282,7 @@ struct BatchStream {
     // byte: the stream handles at most 4 GiB.
     uint32_t lo, hi;          // the bytes [lo, hi) are the data; lo < 16
     uint32_t rows, next_row;
+    uint32_t fold_to;         // rows from here on pass through the ring without entering the CRC (see segment())
     uint32_t acc[4];
     lds_u32 *ring;
     int lane;
@@ -298,11 +299,25 @@ struct BatchStream {
         hi = (uint32_t)(uni64(hi_) - grid);
         rows = (hi + kRowBytes - 1) / kRowBytes;
         next_row = 0;
+        fold_to = 0xffffffffu;
         ring = ring_;
         lane = lane_;
         lane_ptr = base + grid + (uint64_t)lane * 16;
         acc[0] = acc[1] = acc[2] = acc[3] = 0;
     }
+
+    // The stream of one piece of a batch whose CRC is taken piece by piece: it
+    // starts at row `row0` with an empty accumulator (folding nothing gives the piece
+    // itself) and folds the rows below `to`; rows from there on only pass through
+    // the ring, for the record that straddles the piece's end.
+    __device__ __forceinline__ void segment(uint32_t row0, uint32_t to) {
+        next_row = row0;
+        fold_to = to < rows ? to : 0xffffffffu;
+    }
+
+    // The rows only pass through the ring for the walk (the batch's CRC comes from
+    // its chunks); rows nobody reads may then be skipped.
+    __device__ __forceinline__ void pass_through() { fold_to = 0; }
 
     // first row that does not touch a byte below offset `x`
     __device__ __forceinline__ uint32_t row_after(uint32_t x) const {
@@ -333,7 +348,7 @@ struct BatchStream {
         uint32_t slot = Cfg::slot_of(r);
         *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4) = v;
         if (slot == 0 && lane < kRingGuard / 16) *(lds_u128 *)(ring + kRingBytes / 4 + lane * 4) = v;
-        if (fold) {
+        if (fold && r < fold_to) {
             uint32_t nx[4] = {v.x, v.y, v.z, v.w};
             crc_fold_row(acc, nx, lane);
         }
@@ -342,7 +357,7 @@ struct BatchStream {
     // Without a CRC to take, rows that lie before everything a round up to row
     // `target` reads need not be loaded: the ring holds kRows rows.
     __device__ __forceinline__ void skip_before(uint32_t target) {
-        if (!fold && target > next_row + (uint32_t)kRows_) next_row = target - (uint32_t)kRows_;
+        if ((!fold || fold_to == 0) && target > next_row + (uint32_t)kRows_) next_row = target - (uint32_t)kRows_;
     }
 
     // The first and the last row were folded as loaded: take out the bytes that
@@ -350,7 +365,7 @@ struct BatchStream {
     // value 0xFFFFFFFF).  The fold is linear, so this is an XOR into the
     // accumulator, before the next row is folded.
     __device__ __forceinline__ void fix_edge(uint32_t r) {
-        if (!fold) return;
+        if (!fold || fold_to == 0) return;
         uint32_t slot = Cfg::slot_of(r);
         u32x4 raw = *(lds_u128 *)(ring + slot * (kRowBytes / 4) + lane * 4);
         uint64_t addr = (uint64_t)r * kRowBytes + (uint64_t)lane * 16;
@@ -394,7 +409,7 @@ struct BatchStream {
             }
         }
         next_row += n;
-        if (n && next_row == rows && rows > 1) fix_edge(rows - 1);
+        if (n && next_row == rows && rows > 1 && fold_to > rows) fix_edge(rows - 1);
     }
 
     // Rows up to (not including) `target`, for the start of a batch and for what the
@@ -427,6 +442,17 @@ struct BatchStream {
             load(q, n);
             take_loaded(q, n);
         }
+    }
+
+    // The residue of the rows [row0, to) of segment(): the piece's bytes, zero padded
+    // to the end of its last row, times x^32 mod P (what crc_rows() returns); of the
+    // batch's last piece with the padding divided out.
+    __device__ __forceinline__ uint32_t finish_segment(uint32_t to, const CrcTables *t) {
+        to = to < rows ? to : rows;
+        if (next_row < to) pull(to);
+        uint32_t r = crc_row_residue(acc, lane, t);
+        if (to == rows) r = gf_mulmod(r, t->inv8[rows * kRowBytes - hi]);
+        return r;
     }
 
     // the CRC-32C of [lo, hi)

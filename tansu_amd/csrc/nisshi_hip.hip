@@ -44,13 +44,14 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 // Internal per-batch flags
 constexpr uint32_t kFlagExact = 1u;   // needs the sequential walk
 constexpr uint32_t kFlagMore = 2u;    // more headers than the slots it was expected to need: walked again
-constexpr uint32_t kFlagBig = 4u;     // CRC from its chunks, records by the second pass
+constexpr uint32_t kFlagSeg = 4u;     // CRC and records chunk by chunk, a wave each (chunk_kernel); decode_fused_kernel checks that the chunks join up
 
 struct Work {
     uint32_t *alloc_count;  // record slots the batch gets
     uint32_t *n_chunks;     // CRC work items of the batch
     uint32_t *chunk_base;   // encode: exclusive scan of n_chunks, n + 1 entries; decode: see blk_chunks
     uint32_t *partial;      // one residue per CRC work item
+    uint32_t *seg_info;     // four words per CRC work item of a batch decoded chunk by chunk: see segment_wave
     uint32_t *flags;
     // Where a batch's records and headers go follows from sums over the batches
     // before it, in two levels: a batch's place among the kSumBlock batches of its
@@ -73,6 +74,8 @@ struct Work {
 };
 
 constexpr uint32_t kBigChunks = 8;        // from this many 64 KiB chunks on a batch's CRC is taken chunk by chunk
+constexpr uint32_t kSegChunks = 2;        // from this many on, a batch of small records may be decoded chunk by chunk too
+constexpr uint32_t kSegRecordMax = 1024;  // "small": the first record has at most this many bytes
 constexpr uint32_t kSumBlock = 256;       // batches a block of the two-level sums
 constexpr uint32_t kSumDirect = 128;      // up to this many blocks the consumers add the block sums themselves
 
@@ -81,7 +84,9 @@ constexpr uint32_t kSumDirect = 128;      // up to this many blocks the consumer
 // The header count of a batch's first record (0 when that record does not decode),
 // and with `all` the sum over all its records by the sequential walk (0 when any
 // of them does not decode): what the batch is expected to need of header slots.
-__device__ inline uint32_t expected_headers(const uint8_t *data, uint32_t data_len, uint32_t count, bool all) {
+__device__ inline uint32_t expected_headers(const uint8_t *data, uint32_t data_len, uint32_t count, bool all,
+                                            uint32_t &first_size) {
+    first_size = 0;  // the bytes of the first record, its length varint included; 0: not known
     Reader rd(data, data_len);
     uint32_t pos = 0;
     uint64_t sum = 0;
@@ -92,6 +97,10 @@ __device__ inline uint32_t expected_headers(const uint8_t *data, uint32_t data_l
         if ((uint64_t)f.hdr_count * 2 > rd.len - pos) return 0;  // a header is at least two bytes
         if (!all) {
             first = (uint32_t)f.hdr_count;
+            if (f.length >= 0) {
+                uint32_t z = (uint32_t)f.length << 1;
+                first_size = (uint32_t)f.length + (z < (1u << 7) ? 1u : z < (1u << 14) ? 2u : z < (1u << 21) ? 3u : z < (1u << 28) ? 4u : 5u);
+            }
             break;
         }
         for (int32_t j = 0; j < f.hdr_count; j++) {
@@ -134,7 +143,7 @@ __device__ inline uint64_t block_exclusive_scan64(uint64_t v, uint64_t *lds, uin
 // it is expected to need (high half).
 __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t *batch_off, uint32_t b, int by_value,
                                             const nisshi_columns &c, const Work &w, uint32_t count_small,
-                                            uint32_t &chunk_items) {
+                                            uint32_t seg_chunks, uint32_t &chunk_items) {
     const uint8_t *p = blob + batch_off[b];
     uint64_t len = batch_off[b + 1] - batch_off[b];
     int st = NISSHI_OK;
@@ -267,27 +276,32 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
         if (hi == lo) chunks = 1;
     }
     w.n_chunks[b] = chunks;
-    chunk_items = chunks >= kBigChunks ? chunks : 0;
     // header slots: small batches of a call of small batches are counted exactly
     // (they are walked a lane each, tiny_batch_kernel), the others expected from
     // their first record
-    uint32_t expect = 0;
+    uint32_t expect = 0, first_size = 0;
     if (fits && record_count)
-        expect = expected_headers(p + 61, data_len, record_count, count_small && len <= count_small);
+        expect = expected_headers(p + 61, data_len, record_count, count_small && len <= count_small, first_size);
     w.hdr_pred[b] = expect;
+    // A large batch of small records is decoded chunk by chunk (segment_wave); a
+    // large batch of anything else gets its CRC from its chunks and its records
+    // from one wave.  Either way its chunks are work items.
+    bool segmented = fits && chunks >= seg_chunks && first_size != 0 && first_size <= kSegRecordMax;
+    if (segmented) w.flags[b] |= kFlagSeg;
+    chunk_items = segmented || chunks >= kBigChunks ? chunks : 0;
     w.hdr_need[b] = 0;
     return ((uint64_t)expect << 32) | (fits ? record_count : 0u);
 }
 
 __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
-                                    int by_value, nisshi_columns c, Work w, uint32_t count_small) {
+                                    int by_value, nisshi_columns c, Work w, uint32_t count_small, uint32_t seg_chunks) {
     __shared__ uint64_t wave_sums[kSumBlock >> 6];
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     // the call's totals start at zero: their first users are the kernels after this one
     if (b < 8) w.totals[b] = 0;
     uint64_t mine = 0;  // record slots in the low half, expected header slots in the high half
     uint32_t items = 0;  // CRC work items: those of large batches
-    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, items);
+    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, seg_chunks, items);
     uint64_t total;
     uint64_t before = block_exclusive_scan64(mine, wave_sums, total);
     if (b < n) {
@@ -416,60 +430,6 @@ __device__ __forceinline__ uint32_t chunk_first(const Work &w, uint32_t b, bool 
         for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
     }
     return uni(v + w.chunk_base[b]);
-}
-
-// The same items by the decoder's numbering: a block of batches from the block
-// sums (every wave adds them up itself, or finds its way in the running sums),
-// the batch within the block by binary search.  Nothing to do, which is the usual
-// case, costs a wave two loads a lane.
-__device__ __forceinline__ void crc_chunk_items_blocked(uint32_t first, uint32_t stride, const uint8_t *blob,
-                                                        const uint64_t *batch_off, const int32_t *batch_length,
-                                                        uint32_t n, uint32_t *crc_out, const Work &w,
-                                                        const CrcTables *t, int lane, bool prefixed) {
-    uint32_t n_blocks = (n + kSumBlock - 1) / kSumBlock;
-    uint32_t ex0 = 0, ex1 = 0, total;
-    if (prefixed) {
-        total = w.blk_chunks[n_blocks];
-    } else {  // n_blocks <= kSumDirect = 128: lane j holds the sums before blocks j and j + 64
-        uint32_t s0 = (uint32_t)lane < n_blocks ? w.blk_chunks[lane] : 0;
-        uint32_t s1 = (uint32_t)lane + 64 < n_blocks ? w.blk_chunks[lane + 64] : 0;
-        uint32_t i0 = s0, i1 = s1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t u0 = __shfl_up(i0, d, 64), u1 = __shfl_up(i1, d, 64);
-            if (lane >= d) i0 += u0, i1 += u1;
-        }
-        i1 += (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
-        total = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
-        ex0 = i0 - s0;
-        ex1 = i1 - s1;
-    }
-    total = uni(total);
-    for (uint32_t item = first; item < total; item += stride) {
-        uint32_t blk, base;
-        if (prefixed) {
-            uint32_t lo_k = 0, hi_k = n_blocks;  // largest block whose running sum is <= item
-            while (hi_k - lo_k > 1) {
-                uint32_t mid = (lo_k + hi_k) >> 1;
-                if (w.blk_chunks[mid] <= item) lo_k = mid; else hi_k = mid;
-            }
-            blk = lo_k;
-            base = w.blk_chunks[blk];
-        } else {
-            uint64_t m0 = __ballot((uint32_t)lane < n_blocks && ex0 <= item);
-            uint64_t m1 = __ballot((uint32_t)lane + 64 < n_blocks && ex1 <= item);
-            uint32_t top = m1 ? 63u - (uint32_t)__builtin_clzll(m1) : 63u - (uint32_t)__builtin_clzll(m0);
-            blk = m1 ? top + 64 : top;
-            base = (uint32_t)__builtin_amdgcn_readlane((int)(m1 ? ex1 : ex0), (int)top);
-        }
-        uint32_t local = item - base;
-        uint32_t lo_b = blk * kSumBlock, hi_b = lo_b + kSumBlock < n ? lo_b + kSumBlock : n;
-        while (hi_b - lo_b > 1) {  // largest batch of the block whose first item is <= local
-            uint32_t mid = (lo_b + hi_b) >> 1;
-            if (w.chunk_base[mid] <= local) lo_b = mid; else hi_b = mid;
-        }
-        crc_chunk_one(item, lo_b, local - w.chunk_base[lo_b], blob, batch_off, batch_length, crc_out, w, t, lane);
-    }
 }
 
 // One wave per work item, as many passes as the grid needs.
@@ -749,6 +709,7 @@ struct HeaderSlots {
 constexpr int kWalkDone = 0;
 constexpr int kWalkExact = 1;   // a record that does not decode, or whose length disagrees: exact_walk
 constexpr int kWalkChain = 3;   // records whose sizes or shapes change from one to the next: walk_chain
+constexpr int kWalkFull = 4;    // the walk of a piece of a batch only: the header slots ran out
 
 // ---- the streamed walk
 //
@@ -912,10 +873,15 @@ __device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring,
 // the shape in hand, learning the first one's shape when it does not fit, and
 // emits the records that fit.  On kWalkChain *k_out and *pos_out say where the
 // chained walk goes on.
+//
+// The walk starts at record *k_out, byte *pos_out.  `seg` (the same in every lane):
+// the walk of one piece of a batch, which takes the records that start below
+// pos_end and leaves the batch's status alone.
 template <int kRows, bool kFold>
 __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c, uint32_t rec_base, HeaderSlots &slots,
                                              BatchStream<kRows, kFold> &stream, lds_u128 *tab, int lane,
-                                             uint32_t *k_out, uint32_t *pos_out) {
+                                             uint32_t *k_out, uint32_t *pos_out, bool seg = false,
+                                             uint32_t pos_end = 0xffffffffu) {
     uint32_t count = uni(c.record_count[b]);
     uint64_t rbase = rec_base;
     uint32_t data_len = uni(c.data_len[b]);
@@ -994,7 +960,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         uint32_t n = sz ? kReach / sz : (uint32_t)kWave;
         return n < (uint32_t)kWave ? n : (uint32_t)kWave;
     };
-    uint32_t pos = 0, k = 0;
+    uint32_t pos = uni(*pos_out), k = uni(*k_out);
     uint32_t S = count ? data_len / count : 0;
     uint32_t cap = reach(S);
     int st = kWalkDone;
@@ -1016,7 +982,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     // ring at the end of the pass, as far as the round after turned out to need
     // them.  (One exit from the loop, and no jumps out of nested blocks: the values
     // that steer it then stay in scalar registers.)
-    while (k < count) {
+    while (k < count && pos < pos_end) {
         pos = uni(pos);
         S = uni(S);
         k = uni(k);
@@ -1112,6 +1078,10 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                 break;
             }
         }
+        if (seg && m) {  // only the records that start inside the piece
+            uint64_t inside = __ballot((uint32_t)lane < m && start < pos_end);
+            m = (uint32_t)__builtin_popcountll(inside);
+        }
         strikes = m < kChainBelow && lanes >= 2 * kChainBelow ? strikes + 1 : 0;
         if (strikes >= 2) {
             st = kWalkChain;
@@ -1132,7 +1102,10 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             late.piece = slots.next;
             late.headers = shape.hc ? slots.take_uniform(shape.hc, m, lane, late.slot) : false;
             if (slots.full) {
-                if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+                if (seg)
+                    st = kWalkFull;
+                else if (lane == 0)
+                    c.status[b] = NISSHI_CAPACITY;
                 k = count;  // ends the walk, the batch has its status
             } else {
                 late.any = true;
@@ -1350,7 +1323,8 @@ __device__ __forceinline__ bool ring_varlong(const RingView<kRows> &ring, uint32
 template <int kRows, bool kFold>
 __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const nisshi_columns &c, uint32_t rec_base,
                                           HeaderSlots &slots, BatchStream<kRows, kFold> &stream, int lane,
-                                          uint32_t *k_io, uint32_t *pos_io) {
+                                          uint32_t *k_io, uint32_t *pos_io, bool seg = false,
+                                          uint32_t pos_end = 0xffffffffu) {
     typedef RingView<kRows> Ring;
     uint32_t count = uni(c.record_count[b]);
     uint64_t rbase = rec_base;
@@ -1367,7 +1341,7 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
     uint64_t tmark = __builtin_readcyclecounter();
     uint32_t n_rounds = 0, k_first = k;
 #endif
-    while (k < count) {
+    while (k < count && pos < pos_end) {
         pos = uni(pos);
         k = uni(k);
         PHASE(0)
@@ -1449,6 +1423,19 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
             st = kWalkExact;
             __builtin_amdgcn_s_waitcnt(0x0F70);  // the rows asked for are dropped
             break;
+        }
+        if (seg && stop == 2) {  // (a piece leaves such records to the walk of the whole batch)
+            st = kWalkExact;
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            break;
+        }
+        if (seg) {  // only the records that start inside the piece
+            uint64_t inside = __ballot((uint32_t)lane < n && my_start < pos_end);
+            uint32_t n_in = (uint32_t)__builtin_popcountll(inside);
+            if (n_in < n) {
+                p = (uint32_t)__builtin_amdgcn_readlane((int)my_start, (int)n_in);
+                n = n_in;
+            }
         }
         if (stop == 2) {
             // ---- a record larger than the ring's reach, on its own (large_record); the rows
@@ -1549,7 +1536,10 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
             }
         }
         if (no_room) {
-            if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+            if (seg)
+                st = kWalkFull;
+            else if (lane == 0)
+                c.status[b] = NISSHI_CAPACITY;
             k = count;  // ends the walk, the batch has its status
             __builtin_amdgcn_s_waitcnt(0x0F70);
             break;
@@ -1660,35 +1650,171 @@ __device__ __forceinline__ int walk_batch(const uint8_t *blob, uint32_t b, const
     return st;
 }
 
-// One wave per batch: CRC-32C of the batch streamed just ahead of the record
-// walk through an LDS ring, so the batch is read from HBM once.  Batches of
-// kBigChunks chunks or more get their CRC from their chunks (one wave cannot
-// stream them fast enough: the first workgroups of this grid take the chunks) and
-// their records from second_pass_kernel.
-template <int kRows, int kWaves, int kPack>
-__global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
-                                                          const uint64_t *batch_off, uint32_t n,
-                                                          nisshi_columns c, Work w, uint64_t rec_cap,
-                                                          uint64_t hdr_cap, const CrcTables *t,
-                                                          uint32_t chunk_groups, uint32_t prefixed,
-                                                          const uint64_t *before) {
-    // kPack waves a workgroup, each with a batch, a ring and a shape table of its
-    // own: no wave waits for another (there is no barrier below)
-    __shared__ __attribute__((aligned(16))) uint32_t rings[kPack][RingCfg<kRows>::kRingWords];
-    __shared__ __attribute__((aligned(16))) uint32_t shape_tabs[kPack][kShapeWords];
-    int lane = threadIdx.x & 63;
-    uint32_t wave = uni(threadIdx.x >> 6);
-    uint32_t *ring = rings[wave], *shape_tab = shape_tabs[wave];
-    // The first chunk_groups workgroups take the CRC work items of the batches of
-    // kBigChunks chunks and more (none, most of the time): in this grid rather than
-    // in a launch of their own, and ahead of the batches so that they start first.
-    if (blockIdx.x < chunk_groups) {
-        crc_chunk_items_blocked(blockIdx.x * kPack + wave, chunk_groups * kPack, blob, batch_off, c.batch_length, n,
-                                c.crc_computed, w, t, lane, prefixed != 0);
-        return;
+
+// ---- large batches of small records, a wave a 64 KiB chunk
+//
+// The wave of chunk j of such a batch takes the chunk's share of the CRC and the
+// records that start inside the chunk.  It cannot know where the chunk's first
+// record starts, nor which record of the batch that is, so it makes a guess and
+// the guesses are checked when all the chunks are done (segments_join): the
+// start is the first position at or after the chunk's first byte from which three
+// records in a row look like records (find_record_start), the record's index is its
+// offset delta (a producer numbers the records of a batch 0, 1, 2 ...; a batch that
+// does not is decoded by one wave, as a large batch of large records is), and
+// every record has as many headers as the batch's first.  Per chunk the wave
+// leaves {start, index, end, index at the end} in w.seg_info; a batch is decoded
+// when chunk 0 starts at byte 0 with record 0, every chunk ends where the next
+// starts, with its index, and the last ends at record_count (chunks in which no
+// record was found may follow, the tail of the last record).  By induction every
+// chunk then started on a record, with the index the sequential walk would have
+// given it, so the columns are the sequential walk's.  When the chunks do not join
+// up, whatever they stored is overwritten by the walk of the whole batch.
+constexpr uint32_t kSegFailed = 0xffffffffu;
+constexpr uint32_t kSegNone = 0xfffffffeu;  // no record starts in the chunk: right when the batch's records end before it
+constexpr uint32_t kSegScanBytes = kSegRecordMax + 64;
+
+// One record's claim to be a record, at byte q of the record data: its size and
+// its offset delta.  Only a filter; nothing is concluded from it.
+template <int kRows>
+__device__ __forceinline__ bool plausible_record(const RingView<kRows> &ring, uint32_t bias, uint32_t q, uint32_t data_len,
+                                                 uint32_t &size, int32_t &od) {
+    uint32_t used, t_used, o_used;
+    int32_t len;
+    int64_t ts;
+    uint64_t w0 = ring.read64(q + bias);
+    bool ok = q < data_len && fast_varint(w0, used, len) && used <= 2 && len >= 6;
+    size = ok ? used + (uint32_t)len : 0;
+    ok = ok && size <= data_len - q && ((w0 >> (8 * used)) & 0xffu) == 0;  // attributes: no bit is in use
+    uint32_t at = ok ? q + used + 1 : 0;
+    ok = fast_varlong((uint32_t)ring.read64(at + bias), t_used, ts) && ok;
+    at += ok ? t_used : 0;
+    ok = fast_varint(ring.read64(at + bias), o_used, od) && ok;
+    return ok && od >= 0;
+}
+
+// The first position in [x, x + kSegScanBytes) of the record data where three
+// records in a row are plausible, with offset deltas that count up by one (fewer
+// when the batch's last record comes first).  The ring holds the rows that cover
+// the scan and three records of kSegRecordMax bytes behind it.
+template <int kRows>
+__device__ __forceinline__ bool find_record_start(const RingView<kRows> &ring, uint32_t bias, uint32_t x, uint32_t data_len,
+                                                  uint32_t count, int lane, uint32_t &pos0, uint32_t &k0) {
+    for (uint32_t base = x; base < x + kSegScanBytes; base += kWave) {
+        uint32_t q = base + (uint32_t)lane, size;
+        int32_t od0, od;
+        bool ok = plausible_record(ring, bias, q, data_len, size, od0);
+        ok = ok && size <= kSegRecordMax && (uint32_t)od0 < count;
+        uint32_t next = q + size;
+        int32_t want = od0 + 1;
+#pragma unroll 1
+        for (int hop = 0; hop < 2; hop++) {
+            bool more = ok && (uint32_t)want < count;  // the batch's last record has none behind it
+            bool good = plausible_record(ring, bias, more ? next : 0u, data_len, size, od);
+            ok = ok && (!more || (good && od == want && size <= kSegRecordMax));
+            next += more ? size : 0;
+            want += 1;
+        }
+        uint64_t found = __ballot(ok);
+        if (found) {
+            uint32_t first = (uint32_t)__ffsll((long long)found) - 1;
+            pos0 = base + first;
+            k0 = (uint32_t)__builtin_amdgcn_readlane(od0, (int)first);
+            return true;
+        }
     }
-    uint32_t b = (blockIdx.x - chunk_groups) * kPack + wave;
-    if (b >= n) return;
+    return false;
+}
+
+// Whether the chunks of batch b, whose work items start at `first`, join up.
+__device__ __forceinline__ bool segments_join(const Work &w, uint32_t first, uint32_t chunks, uint32_t count, int lane) {
+    bool good = true;
+    for (uint32_t j = (uint32_t)lane; j < chunks; j += kWave) {
+        u32x4 mine = *reinterpret_cast<const u32x4 *>(w.seg_info + 4 * (uint64_t)(first + j));
+        good = good && mine.w != kSegFailed;
+        if (j == 0) good = good && mine.x == 0 && mine.y == 0;
+        if (j + 1 < chunks) {
+            u32x4 next = *reinterpret_cast<const u32x4 *>(w.seg_info + 4 * (uint64_t)(first + j + 1));
+            if (mine.w == kSegNone)
+                good = good && next.w == kSegNone;
+            else if (next.w == kSegNone)
+                good = good && mine.w == count;
+            else
+                good = good && mine.z == next.x && mine.w == next.y;
+        } else {
+            good = good && (mine.w == kSegNone || mine.w == count);
+        }
+    }
+    return __all(good);
+}
+
+// The CRC work items by the decoder's numbering, for a wave that goes through
+// some of them: a block of batches from the block sums (every wave adds them up
+// itself, or finds its way in the running sums), the batch within the block by
+// binary search.  No items, which is the usual case, costs a wave two loads a lane.
+struct ChunkItems {
+    uint32_t n, n_blocks, total, ex0, ex1;
+    bool prefixed;
+
+    __device__ __forceinline__ void init(const Work &w, uint32_t n_, bool prefixed_, int lane) {
+        n = n_;
+        prefixed = prefixed_;
+        n_blocks = (n + kSumBlock - 1) / kSumBlock;
+        ex0 = ex1 = 0;
+        if (prefixed) {
+            total = w.blk_chunks[n_blocks];
+        } else {  // n_blocks <= kSumDirect = 128: lane j holds the sums before blocks j and j + 64
+            uint32_t s0 = (uint32_t)lane < n_blocks ? w.blk_chunks[lane] : 0;
+            uint32_t s1 = (uint32_t)lane + 64 < n_blocks ? w.blk_chunks[lane + 64] : 0;
+            uint32_t i0 = s0, i1 = s1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t u0 = __shfl_up(i0, d, 64), u1 = __shfl_up(i1, d, 64);
+                if (lane >= d) i0 += u0, i1 += u1;
+            }
+            i1 += (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+            total = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+            ex0 = i0 - s0;
+            ex1 = i1 - s1;
+        }
+        total = uni(total);
+    }
+
+    // item -> (batch, chunk)
+    __device__ __forceinline__ void locate(const Work &w, uint32_t item, int lane, uint32_t &b, uint32_t &chunk) const {
+        uint32_t blk, base;
+        if (prefixed) {
+            uint32_t lo_k = 0, hi_k = n_blocks;  // largest block whose running sum is <= item
+            while (hi_k - lo_k > 1) {
+                uint32_t mid = (lo_k + hi_k) >> 1;
+                if (w.blk_chunks[mid] <= item) lo_k = mid; else hi_k = mid;
+            }
+            blk = lo_k;
+            base = w.blk_chunks[blk];
+        } else {
+            uint64_t m0 = __ballot((uint32_t)lane < n_blocks && ex0 <= item);
+            uint64_t m1 = __ballot((uint32_t)lane + 64 < n_blocks && ex1 <= item);
+            uint32_t top = m1 ? 63u - (uint32_t)__builtin_clzll(m1) : 63u - (uint32_t)__builtin_clzll(m0);
+            blk = m1 ? top + 64 : top;
+            base = (uint32_t)__builtin_amdgcn_readlane((int)(m1 ? ex1 : ex0), (int)top);
+        }
+        uint32_t local = item - base;
+        uint32_t lo_b = blk * kSumBlock, hi_b = lo_b + kSumBlock < n ? lo_b + kSumBlock : n;
+        while (hi_b - lo_b > 1) {  // largest batch of the block whose first item is <= local
+            uint32_t mid = (lo_b + hi_b) >> 1;
+            if (w.chunk_base[mid] <= local) lo_b = mid; else hi_b = mid;
+        }
+        b = uni(lo_b);
+        chunk = uni(local - w.chunk_base[lo_b]);
+    }
+};
+
+// One unit of decode_fused_kernel's work: batch b, or with `seg` its chunk `chunk`
+// (CRC work item `mine`).  `seg` is a constant where this is called.
+template <int kRows>
+__device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk, uint32_t mine, const uint8_t *blob,
+                                            const uint64_t *batch_off, uint32_t n, const nisshi_columns &c, const Work &w,
+                                            uint64_t rec_cap, uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed,
+                                            const uint64_t *before, uint32_t *ring, uint32_t *shape_tab, int lane) {
 #ifdef NISSHI_PHASES
     uint64_t tl[6];
     uint64_t wall0 = wall_clock64();
@@ -1697,9 +1823,10 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     uint32_t chunks = uni(w.n_chunks[b]);
     uint32_t flags = uni(w.flags[b]);
     int status = (int)uni((uint32_t)c.status[b]);
-    // The batch's first rows are asked for before anything else is worked out: where
-    // its records and headers go takes a few trips to the L2, and the rows come from
-    // further away.
+    uint32_t count = uni(c.record_count[b]);
+    // The unit's first rows are asked for before anything else is worked out: where
+    // the batch's records and headers go takes a few trips to the L2, and the rows
+    // come from further away.
 #ifdef NISSHI_DIAG_NOFOLD
     BatchStream<kRows, false> stream;
 #else
@@ -1708,14 +1835,48 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     constexpr int kAhead = RingCfg<kRows>::kAhead;
     u32x4 first_rows[kAhead];
     uint32_t n_first = 0;
-    bool streamed = chunks != 0 && chunks < kBigChunks;
+    // A batch whose chunks were work items of chunk_kernel, which is through with
+    // them: its CRC from their residues; and its records are there, if they were
+    // decoded chunk by chunk and the chunks join up.  Otherwise the batch is walked
+    // here like any other, but for the CRC.
+    bool in_chunks = !seg && (chunks >= kBigChunks || (flags & kFlagSeg));
+    bool joined_up = false;
+    if (in_chunks) {
+        uint32_t first_item = chunk_first(w, b, prefixed != 0, lane);
+        uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, chunks, w.partial + first_item, t, lane);
+        if (lane == 0) c.crc_computed[b] = v;
+        joined_up = (flags & kFlagSeg) && status == NISSHI_OK && segments_join(w, first_item, chunks, count, lane);
+#ifdef NISSHI_DIAG_JOINS  // diagnostic builds only: batches whose chunks did not join up, counted as sequential walks
+        if ((flags & kFlagSeg) && !joined_up && lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
+            printf("no join: b=%u chunks=%u count=%u\n", b, chunks, count);
+            for (uint32_t j = 0; j < chunks && j < 20; j++) {
+                const uint32_t *q = w.seg_info + 4 * (uint64_t)(first_item + j);
+                printf("   %u: start %u index %u end %u index %u\n", j, q[0], q[1], q[2], q[3]);
+            }
+        }
+#endif
+    }
+    bool streamed = chunks != 0 && !joined_up && !(in_chunks && status != NISSHI_OK);  // (nothing to walk, and the CRC is there)
 #ifdef NISSHI_DIAG_NOSTREAM  // diagnostic builds only: what the kernel costs without parts of its work
     streamed = false;
 #endif
+    uint32_t row0 = chunk * kChunkRows, fold_to = seg ? row0 + kChunkRows : 0xffffffffu;
+    uint32_t bias = 0, x = 0;  // x: the chunk's first byte as a position in the record data
     if (streamed) {
         uint64_t lo = batch_off[b] + 21;
         stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
-        n_first = stream.rows < (uint32_t)kAhead ? stream.rows : (uint32_t)kAhead;
+        bias = 40 + stream.lo;
+        if (seg) {
+            stream.segment(row0, fold_to);
+            x = chunk ? row0 * kRowBytes - bias : 0;
+            // what the search for the chunk's first record reads
+            n_first = stream.row_after(bias + x + kSegScanBytes + 3 * kSegRecordMax + 80) - row0;
+        } else {
+            if (in_chunks) stream.pass_through();
+            n_first = stream.rows;
+        }
+        n_first = n_first < (uint32_t)kAhead ? n_first : (uint32_t)kAhead;
         stream.load(first_rows, n_first);
     }
     // where the batch's records and headers go
@@ -1725,33 +1886,33 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     tl[1] = __builtin_readcyclecounter();
 #endif
     uint32_t expect = uni(w.hdr_pred[b]);
-    if (lane == 0) {
-        c.rec_base[b] = rec_base;
-        c.hdr_base[b] = hdr_base;
-        if (b + 1 == n) {  // the last batch: the ends of the record slots and of the expected header slots
-            w.totals[0] = (uint64_t)rec_base + w.alloc_count[b];
-            w.totals[6] = (uint64_t)hdr_base + expect;
-            atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 1), (unsigned long long)hdr_base + expect);
-        }
-    }
-    if (chunks == 0) {
-        // done already (a small batch of a call of small batches), or no CRC to take: the header failed early
-        if (lane == 0 && status != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
-        return;
-    }
-    if (chunks >= kBigChunks) {
+    if (!seg) {
         if (lane == 0) {
-            w.flags[b] = flags | kFlagBig;
-            list_append(w, b);
+            c.rec_base[b] = rec_base;
+            c.hdr_base[b] = hdr_base;
+            if (b + 1 == n) {  // the last batch: the ends of the record slots and of the expected header slots
+                w.totals[0] = (uint64_t)rec_base + w.alloc_count[b];
+                w.totals[6] = (uint64_t)hdr_base + expect;
+                atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 1), (unsigned long long)hdr_base + expect);
+            }
         }
-        return;
+        if (chunks == 0) {
+            // done already (a small batch of a call of small batches), or no CRC to take: the header failed early
+            if (lane == 0 && status != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
+            return;
+        }
+        if (joined_up) {
+            if (lane == 0) c.hdr_count[b] = expect;
+            return;
+        }
     }
 #ifdef NISSHI_DIAG_NOSTREAM
     return;
 #endif
     bool do_walk = status == NISSHI_OK && !(flags & kFlagExact);
-    if (do_walk && (uint64_t)rec_base + uni(c.record_count[b]) > rec_cap) {
-        if (lane == 0) c.status[b] = NISSHI_CAPACITY;
+    if (do_walk && (uint64_t)rec_base + count > rec_cap) {
+        // (of a batch in chunks the second pass says so)
+        if (!seg && lane == 0) c.status[b] = NISSHI_CAPACITY;
         status = NISSHI_CAPACITY;
         do_walk = false;
     }
@@ -1759,18 +1920,41 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     do_walk = false;
 #endif
     stream.take_loaded(first_rows, n_first);
-    bool exact = status == NISSHI_OK && (flags & kFlagExact);
+    bool exact = !seg && status == NISSHI_OK && (flags & kFlagExact);
 #ifdef NISSHI_PHASES
     tl[2] = __builtin_readcyclecounter();
 #endif
+    // ---- where the unit's walk starts and ends
+    uint32_t k0 = 0, pos0 = 0, pos_end = 0xffffffffu, hdr_first = hdr_base, hdr_slots = expect;
+    bool none = false;  // seg: no record starts in the chunk
+    if (seg && do_walk) {
+        lds_order();
+        if (chunk) {
+            uint32_t data_len = uni(c.data_len[b]);
+            do_walk = x < data_len && find_record_start(RingView<kRows>{stream.ring}, bias, x, data_len, count, lane, pos0, k0);
+            none = !do_walk;
+        }
+        pos0 = uni(pos0);
+        k0 = uni(k0);
+        // every record is taken to have the header count of the batch's first: the chunk's headers start k0 such records in
+        uint32_t hc = count ? expect / count : 0;
+        hdr_first += k0 * hc;
+        hdr_slots -= k0 * hc;
+        if (chunk + 1 < chunks) pos_end = fold_to * kRowBytes - bias;
+    }
+    uint32_t k = k0, pos = pos0;
+    bool joined = false;  // seg: the chunk's records are decoded, as far as the chunk can tell
     if (do_walk) {
         HeaderSlots slots;
-        slots.init(hdr_base, expect, hdr_cap);
-        int st = walk_batch(blob, b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane);
+        slots.init(hdr_first, hdr_slots, hdr_cap);
+        int st = walk_streamed(b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane, &k, &pos, seg, pos_end);
+        if (st == kWalkChain) st = walk_chain(blob, b, c, rec_base, slots, stream, lane, &k, &pos, seg, pos_end);
 #ifdef NISSHI_PHASES
         tl[3] = __builtin_readcyclecounter();
 #endif
-        if (st == kWalkExact) {
+        if (seg) {
+            joined = st == kWalkDone && !slots.over && !slots.full && slots.count == (k - k0) * (count ? expect / count : 0);
+        } else if (st == kWalkExact) {
             exact = true;
         } else if (lane == 0) {
             c.hdr_count[b] = slots.count;
@@ -1782,7 +1966,7 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
                 list_append(w, b);
             }
         }
-    } else if (lane == 0 && status != NISSHI_OK) {
+    } else if (!seg && lane == 0 && status != NISSHI_OK) {
         atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
     }
     if (exact && lane == 0) {
@@ -1803,14 +1987,71 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
             list_append(w, b);
         }
     }
-    uint32_t v = stream.finish(t);
-    if (lane == 0) c.crc_computed[b] = v;
+    if (seg) {
+        uint32_t r = stream.finish_segment(fold_to, t);
+        if (lane == 0) {
+            w.partial[mine] = r;
+            *reinterpret_cast<u32x4 *>(w.seg_info + 4 * (uint64_t)mine) =
+                u32x4{pos0, k0, pos, joined ? k : none ? kSegNone : kSegFailed};
+        }
+    } else if (!in_chunks) {
+        uint32_t v = stream.finish(t);
+        if (lane == 0) c.crc_computed[b] = v;
+    }
+    lds_order();
 #ifdef NISSHI_PHASES
     tl[4] = __builtin_readcyclecounter();
     if (lane == 0 && (b % 1024) == 7)
         printf("fused b=%u wall=%lu..%lu bases=%lu init=%lu walk=%lu finish=%lu\n", b, wall0, wall_clock64(), tl[1] - tl[0],
                tl[2] - tl[1], tl[3] - tl[2], tl[4] - tl[3]);
 #endif
+}
+
+// The chunks of large batches, a wave each (as many passes as the grid needs),
+// ahead of decode_fused_kernel: of a batch of small records a chunk's wave takes
+// the chunk's share of the CRC and of the records (see segments_join), of any
+// other batch of kBigChunks chunks and more only the CRC (one wave cannot stream
+// such a batch fast enough; its records are walked by its wave of
+// decode_fused_kernel).  Most calls have no such batch, and every wave is done
+// after two loads a lane.
+template <int kRows>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void chunk_kernel(
+    const uint8_t *blob, const uint64_t *batch_off, uint32_t n, nisshi_columns c, Work w, uint64_t rec_cap,
+    uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed, const uint64_t *before) {
+    __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
+    __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
+    int lane = threadIdx.x & 63;
+    ChunkItems items;
+    items.init(w, n, prefixed != 0, lane);
+    for (uint32_t item = blockIdx.x; item < items.total; item += gridDim.x) {
+        uint32_t b, chunk;
+        items.locate(w, item, lane, b, chunk);
+        if (uni(w.flags[b]) & kFlagSeg)
+            decode_unit<kRows>(true, b, chunk, item, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before, ring,
+                               shape_tab, lane);
+        else
+            crc_chunk_one(item, b, chunk, blob, batch_off, c.batch_length, c.crc_computed, w, t, lane);
+    }
+}
+
+// One wave per batch: CRC-32C of the batch streamed just ahead of the record
+// walk through an LDS ring, so the batch is read from HBM once.
+template <int kRows, int kWaves, int kPack>
+__global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
+                                                          const uint64_t *batch_off, uint32_t n,
+                                                          nisshi_columns c, Work w, uint64_t rec_cap,
+                                                          uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed,
+                                                          const uint64_t *before) {
+    // kPack waves a workgroup, each with a batch, a ring and a shape table of its
+    // own: no wave waits for another (there is no barrier below)
+    __shared__ __attribute__((aligned(16))) uint32_t rings[kPack][RingCfg<kRows>::kRingWords];
+    __shared__ __attribute__((aligned(16))) uint32_t shape_tabs[kPack][kShapeWords];
+    int lane = threadIdx.x & 63;
+    uint32_t wave = uni(threadIdx.x >> 6);
+    uint32_t b = blockIdx.x * kPack + wave;
+    if (b >= n) return;
+    decode_unit<kRows>(false, b, 0, 0, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before, rings[wave],
+                       shape_tabs[wave], lane);
 }
 
 // Batches of a few hundred bytes, a lane each: a workgroup a batch spends more on
@@ -1857,17 +2098,13 @@ __global__ __launch_bounds__(256) void tiny_batch_kernel(const uint8_t *blob, co
     w.flags[b] = 0;
 }
 
-// What decode_fused_kernel left, a wave a batch of its list: batches of kBigChunks
-// chunks and more (the CRC from the chunks' residues, the records by the walk, the
-// batch passing through the ring without a CRC; `big` = 1 handles these and only
-// these), batches that need the sequential walk's stores, and batches whose
-// headers did not fit their expected slots, walked again with slots behind those
-// of all batches (`big` = 0; in a launch after the one for the big batches, which
-// may find more such batches).
+// What decode_fused_kernel left, a wave a batch of its list: batches that need the
+// sequential walk's stores, and batches whose headers did not fit their expected
+// slots, walked again (passing through the ring without a CRC) with slots behind
+// those of all batches.
 template <int kRows>
 __global__ __launch_bounds__(64) void second_pass_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
-                                                         nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap,
-                                                         const CrcTables *t, uint32_t big, uint32_t prefixed) {
+                                                         nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
     __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
     int lane = threadIdx.x & 63;
@@ -1875,26 +2112,13 @@ __global__ __launch_bounds__(64) void second_pass_kernel(const uint8_t *blob, co
     for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
         uint32_t b = uni(w.list[e]);
         uint32_t flags = uni(w.flags[b]);
-        if (((flags & kFlagBig) != 0) != (big != 0)) continue;
-        if (flags & kFlagBig) {
-            const uint32_t *part = w.partial + chunk_first(w, b, prefixed != 0, lane);
-            uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, uni(w.n_chunks[b]), part, t, lane);
-            if (lane == 0) c.crc_computed[b] = v;
-        }
         uint32_t rec_base = uni(c.rec_base[b]);
         uint32_t expect = uni(w.hdr_pred[b]), need = uni(w.hdr_need[b]);
-        int status = (int)uni((uint32_t)c.status[b]);
-        if (status != NISSHI_OK) {  // a big batch whose header failed
-            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
-            continue;
-        }
         uint32_t first = need ? extra_base(w, b, lane) : uni(c.hdr_base[b]);
         uint32_t have = need ? need : expect;
         if (flags & kFlagExact) {
             if (lane == 0) {
                 uint32_t headers = 0;
-                // (a big batch whose record count its data cannot hold comes here unwalked)
-                if (flags & kFlagBig) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
                 int st = exact_walk<true>(blob, b, c, w, rec_base, first, have, hdr_cap, &headers);
                 c.hdr_count[b] = headers;
                 c.hdr_base[b] = first;
@@ -1903,41 +2127,17 @@ __global__ __launch_bounds__(64) void second_pass_kernel(const uint8_t *blob, co
             }
             continue;
         }
-        if ((uint64_t)rec_base + uni(c.record_count[b]) > rec_cap) {
-            if (lane == 0) {
-                c.status[b] = NISSHI_CAPACITY;
-                atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
-            }
-            continue;
-        }
+        // (the batch has record slots: its first walk got through)
         BatchStream<kRows, false> stream;
         uint64_t lo = batch_off[b] + 21;
         stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
         HeaderSlots slots;
         slots.init(first, have, hdr_cap);
-        int st = walk_batch(blob, b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane);
+        walk_batch(blob, b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane);
         if (lane == 0) {
             c.hdr_base[b] = first;
             c.hdr_count[b] = slots.count;
-            if (st == kWalkExact) {
-                // (a big batch only: the others came here because the walk got through)
-                uint32_t headers = 0;
-                int est = exact_walk<false>(blob, b, c, w, rec_base, 0, 0, 0, &headers);
-                atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
-                c.status[b] = est;
-                c.hdr_count[b] = headers;
-                if (est != NISSHI_OK) {
-                    atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
-                } else {
-                    if (headers > expect) note_need(w, b, headers);
-                    w.flags[b] = kFlagExact;  // no longer big: the launch after this one stores it
-                }
-            } else if (c.status[b] != NISSHI_OK) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
-            } else if (slots.over) {
-                note_need(w, b, slots.count);
-                w.flags[b] = kFlagMore;  // walked once more by the launch after this one
-            }
+            if (c.status[b] != NISSHI_OK) atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
         }
         lds_order();
     }

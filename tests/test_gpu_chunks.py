@@ -1,0 +1,139 @@
+"""Large batches of small records are decoded chunk by chunk, a wave a 64 KiB
+chunk, on guesses that are checked afterwards (where a chunk's first record
+starts, which record it is, how many headers a record has); a batch whose chunks
+do not join up is walked by one wave.  Either way the columns are the sequential
+walk's (deflated.rs:431-442 with record.rs:254-277): against the oracle, on batches
+built to take every way through."""
+import struct
+
+import numpy as np
+import pytest
+
+import oracle
+from tansu_amd import columns as C, hip, synth
+from test_gpu_parity import check_against_oracle, crc_patch
+from util import build_batch, offsets_of
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 65536
+
+
+@pytest.fixture(scope="module")
+def codec():
+    c = hip.Codec(0)
+    yield c
+    c.close()
+
+
+def records(n, rng, value=lambda i: 100, headers=lambda i: 0, key=lambda i: b"key%05d" % i, od=lambda i: i,
+            ts=lambda i: i):
+    out = []
+    for i in range(n):
+        v = bytes(rng.integers(0, 256, value(i), dtype=np.uint8))
+        h = [C.Header(b"h%d" % j, b"v%d" % (i % 10)) for j in range(headers(i))]
+        out.append(C.Record(0, 0, ts(i), od(i), key(i), v, h))
+    return out
+
+
+def decode(codec, batches):
+    blob = np.frombuffer(b"".join(batches), dtype=np.uint8).copy()
+    off = offsets_of(batches)
+    crc_patch(codec, blob, off)
+    return check_against_oracle(codec, blob, off)
+
+
+def test_chunks_join(codec):
+    """Records of one kind, 10 000 of them (the offset delta and the timestamp
+    delta grow a byte at 64 and at 8192), and a batch whose records change size
+    and kind in the middle of a chunk, header count unchanged: every chunk joins
+    the next, nothing is walked twice."""
+    rng = np.random.default_rng(1)
+    same = build_batch(dict(base_offset=0, last_offset_delta=9999), records(10000, rng, headers=lambda i: 2))
+    change = build_batch(dict(base_offset=10000, last_offset_delta=5999),
+                         records(6000, rng, value=lambda i: 100 if i < 2500 else 31 + i % 7,
+                                 key=lambda i: None if i > 4000 else b"k%d" % i))
+    assert len(same) > 8 * CHUNK and len(change) > 4 * CHUNK
+    g, c, totals, *_ = decode(codec, [same, change, same])
+    assert (totals.n_failed, totals.n_exact, totals.n_records) == (0, 0, 26000)
+    assert list(g["hdr_count"][:3]) == [20000, 0, 20000]
+    assert (g["crc"][:3] == g["crc_computed"][:3]).all()
+
+
+def test_chunks_that_do_not_join(codec):
+    """What the guesses cannot know: a header count that changes inside the batch, offset
+    deltas with gaps (a compacted batch), bytes inside a value that look like a run of
+    records right where a chunk begins, records that end well before the batch does, and
+    a record count below the records present.  The walk of the whole batch decides."""
+    rng = np.random.default_rng(2)
+    more_headers = build_batch(dict(base_offset=0, last_offset_delta=3999),
+                               records(4000, rng, headers=lambda i: 1 if i < 3000 else 3))
+    fewer_headers = build_batch(dict(base_offset=0, last_offset_delta=3999),
+                                records(4000, rng, headers=lambda i: 2 if i < 1000 else 0))
+    gaps = build_batch(dict(base_offset=0, last_offset_delta=3 * 3999), records(4000, rng, od=lambda i: 3 * i))
+    # a value that covers the start of chunk 1 and holds what looks like records 700, 701, ...
+    fake = b"".join(bytes([2 * 9, 0]) + synth.varint(0) + synth.varint(700 + j) + b"\x01\x02\x03\x04\x05"
+                    for j in range(60))
+    plain = records(3000, rng)
+    first = build_batch(dict(base_offset=0, last_offset_delta=2999), plain)
+    st, cc, _, _ = oracle.decode_columns(first, offsets_of([first]))
+    ends = 61 + cc["val_off"][:3000].astype(np.int64) + 100   # frame offsets of the records' ends
+    at = int(np.searchsorted(ends, 21 + CHUNK - 300))          # the record that ends ~300 bytes before chunk 1
+    plain[at + 1] = C.Record(0, 0, at + 1, at + 1, b"k", fake + bytes(200), [])
+    mimic = build_batch(dict(base_offset=0, last_offset_delta=2999), plain)
+    tail = bytearray(build_batch(dict(base_offset=0, last_offset_delta=1999), records(2000, rng)))
+    tail += bytes(rng.integers(0, 256, 3 * CHUNK, dtype=np.uint8))      # bytes behind the records, inside the batch
+    tail[8:12] = struct.pack(">i", len(tail) - 12)
+    fewer = bytearray(build_batch(dict(base_offset=0, last_offset_delta=3999), records(4000, rng)))
+    fewer[57:61] = struct.pack(">I", 2500)
+    batches = [more_headers, fewer_headers, gaps, mimic, bytes(tail), bytes(fewer)]
+    assert all(len(b) > 2 * CHUNK for b in batches)
+    g, c, totals, *_ = decode(codec, batches)
+    assert list(c["status"][:6]) == [C.OK] * 6
+    assert totals.n_failed == 0 and totals.n_records == 4000 * 3 + 3000 + 2000 + 2500
+    assert list(g["hdr_count"][:6]) == [3000 + 3 * 1000, 2000, 0, 0, 0, 0]
+
+
+def test_chunks_with_records_that_do_not_decode(codec):
+    """A record whose length disagrees with its fields in chunk 2 (the reference takes
+    the fields' word for it and goes on, record.rs:254-277), a record cut short by the
+    end of the data in the last chunk, a count beyond the records: the batch's outcome is
+    the sequential walk's."""
+    rng = np.random.default_rng(3)
+    good = build_batch(dict(base_offset=0, last_offset_delta=3999), records(4000, rng))
+    st, cc, _, _ = oracle.decode_columns(good, offsets_of([good]))
+    wrong = bytearray(good)
+    # record 1500's length varint: two bytes before its attributes byte; its key starts 3 + 2 + 2 bytes further on
+    start = 61 + int(cc["key_off"][1500]) - 1 - 2 - 2 - 1 - 2
+    assert wrong[start + 2] == 0 and start > 21 + 2 * CHUNK
+    wrong[start] ^= 0x02
+    cut = bytearray(good)
+    cut[8:12] = struct.pack(">i", len(cut) - 12 - 40)
+    del cut[-40:]
+    over = bytearray(good)
+    over[57:61] = struct.pack(">I", 4001)
+    batches = [good, bytes(wrong), bytes(cut), bytes(over), good]
+    g, c, totals, *_ = decode(codec, batches)
+    assert [int(s) == C.OK for s in c["status"][:5]] == [True, True, False, False, True]
+    assert totals.n_failed == 2 and totals.n_exact >= 3
+
+
+def test_few_and_many_batches_give_the_same_columns(codec):
+    """A call of few batches takes its batches of 128 KiB and more chunk by chunk, a
+    call of many only those of 512 KiB and more: the same batch decodes to the same
+    columns in both (here through the context's switch for the number of batches)."""
+    import os
+    shape, counts, seed = synth.config("c5", 0.01)
+    blob, off, nr, nh = synth.make_batches(shape, counts, seed)
+    crc_patch(codec, blob, off)
+    g, c, totals, *_ = check_against_oracle(codec, blob, off)
+    os.environ["NISSHI_SEG_FEW_BATCHES"] = "0"
+    try:
+        other = hip.Codec(0)
+        g2, c2, totals2, *_ = check_against_oracle(other, blob, off)
+        other.close()
+    finally:
+        del os.environ["NISSHI_SEG_FEW_BATCHES"]
+    for name in g:
+        assert (g[name] == g2[name]).all(), name
+    assert totals.n_records == totals2.n_records == nr
