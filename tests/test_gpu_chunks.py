@@ -137,3 +137,29 @@ def test_few_and_many_batches_give_the_same_columns(codec):
     for name in g:
         assert (g[name] == g2[name]).all(), name
     assert totals.n_records == totals2.n_records == nr
+
+
+def test_batches_of_many_records_are_written_in_pieces(codec):
+    """The encoder writes a batch of 2048 records and more 1024 records a wave, each
+    piece adding its share to the batch's CRC; a long value inside a piece is copied
+    apart and leaves the CRC to the pass over the output.  Output against the oracle's
+    and against the (canonical) input, CRC field included."""
+    import torch
+    rng = np.random.default_rng(4)
+    plain = build_batch(dict(base_offset=0, last_offset_delta=4999), records(5000, rng, headers=lambda i: i % 3))
+    long_value = build_batch(dict(base_offset=0, last_offset_delta=2999),
+                             records(3000, rng, value=lambda i: 40000 if i == 1700 else 700 if i == 2100 else 50))
+    edge = build_batch(dict(base_offset=0, last_offset_delta=2047), records(2048, rng, value=lambda i: i % 90))
+    small = build_batch(dict(base_offset=0, last_offset_delta=2046), records(2047, rng))
+    batches = [plain, long_value, edge, small, plain]
+    g, c, totals, cols, d_blob, d_off = decode(codec, batches)
+    blob = np.frombuffer(b"".join(batches), dtype=np.uint8)
+    n_b = len(batches)
+    out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=codec.device)
+    out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
+    t = codec.encode_dev(cols, n_b, d_blob, cols.t["data_off"], out, len(blob), out_off)
+    got = out[:t.out_bytes].cpu().numpy().tobytes()
+    st, want, _ = oracle.encode_columns(c, n_b, d_blob.cpu().numpy()[:len(blob)], c["data_off"])
+    assert st == C.OK and got == want
+    # the input but for the CRC fields, which the test's batches carry as the decoder computed them
+    assert got == d_blob.cpu().numpy()[:len(blob)].tobytes()
