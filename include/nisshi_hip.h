@@ -106,7 +106,7 @@ typedef struct nisshi_columns {
     uint64_t *data_off;     /* offset of record_data in the blob */
     uint32_t *data_len;
     uint32_t *rec_base;  /* index of the batch's first record in the record columns */
-    uint32_t *hdr_base;  /* slot of the batch's first header (its headers need not be one run) */
+    uint32_t *hdr_base;  /* slot of the batch's first header; its headers are one run, in record order */
     uint32_t *hdr_count; /* headers in the batch */
     int32_t *status;
     /* per record */
@@ -120,7 +120,7 @@ typedef struct nisshi_columns {
 
 typedef struct nisshi_totals {
     uint64_t n_records;  /* record slots used (a failed batch may leave its slots unused) */
-    uint64_t n_headers;  /* header slots handed out: at least the number of headers (see below) */
+    uint64_t n_headers;  /* header slots in use or set aside: at least the number of headers (see nisshi_hip_decode_dev) */
     uint32_t n_failed;   /* batches whose status is not NISSHI_OK */
     uint32_t n_exact;    /* batches that needed the sequential walk (length disagreed with the fields) */
     uint64_t out_bytes;  /* encode: bytes written */
@@ -129,12 +129,14 @@ typedef struct nisshi_totals {
 typedef struct nisshi_hip_ctx nisshi_hip_ctx;
 
 /* Create a context on a HIP device; fails with NISSHI_DEVICE_ERROR when no
- * usable gfx950 device is present.  There is no CPU fallback.  Two settings are
+ * usable gfx950 device is present.  There is no CPU fallback.  Three settings are
  * read from the environment here: NISSHI_SLICE_BYTES (the slice of the
- * host-buffer decode, see nisshi_hip_decode) and NISSHI_WIDE_RING_FROM (the mean
+ * host-buffer decode, see nisshi_hip_decode), NISSHI_WIDE_RING_FROM (the mean
  * batch size in bytes from which the decode kernel streams a batch through
  * twelve 1 KiB rows of LDS at three waves a SIMD instead of eight at four;
- * default 65536).  Neither changes any result. */
+ * default 65536) and NISSHI_SEG_FEW_BATCHES (calls of fewer batches than this
+ * decode their batches of 128 KiB and more a wave a 64 KiB chunk, calls of more
+ * only those of 512 KiB and more; default 6144).  None changes any result. */
 int nisshi_hip_ctx_create(int device, nisshi_hip_ctx **ctx);
 void nisshi_hip_ctx_destroy(nisshi_hip_ctx *ctx);
 const char *nisshi_hip_status_str(int status);
@@ -165,18 +167,31 @@ int nisshi_hip_count_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t bl
  * waits for the stream and fills *totals.  A batch that fails leaves its
  * status and no valid records; the call still returns NISSHI_OK.
  *
- * Header slots are handed out in runs from one cursor while batches decode in
- * parallel: a record's headers are contiguous from hdr_base, but the order of
- * runs between batches is not defined and a batch may leave up to 4096 slots of
- * its last run unused (four times that for a batch of 448 KiB and more, or one
- * whose records the streamed walk cannot express: several waves walk it, each
- * with runs of its own), so size hdr_cap with that slack (a batch whose headers do not
- * fit gets NISSHI_CAPACITY).  Batches whose records all carry the same number of
- * headers use exactly their header count.  A batch that ends on the sequential
- * walk (totals.n_exact: a record whose length disagrees with its fields, or one
- * that does not decode) starts over with fresh slots and leaves those of its
- * first attempt unused; blob_len + 4096 * n_batches slots in all cover every
- * case (a header is at least two bytes). */
+ * Where records and headers go does not depend on the order the batches decode
+ * in: two decodes of a blob give the same columns, byte for byte.  A batch's
+ * records start at the sum of the record counts of the decodable batches before
+ * it (rec_base).  A batch is expected to have as many headers a record as its
+ * first record has; its headers start at the sum of what the batches before it
+ * are expected to have (hdr_base), in record order, one run.  A batch with more
+ * headers than that gets all of them in one run behind the expected slots of all
+ * batches, again in batch order, and leaves its expected slots unused
+ * (totals.n_headers counts both).  So a call whose batches have the same number
+ * of headers in every record needs exactly its header count of slots, and
+ * blob_len + 1 slots cover every call (a header is at least two bytes).  A batch
+ * whose records or headers do not fit rec_cap or hdr_cap gets NISSHI_CAPACITY.
+ *
+ * d_blob must be 16-byte aligned, as must d_cols->rkey, rval and hdr (they are
+ * read and written sixteen bytes at a time) and timestamp_delta 8-byte aligned;
+ * the call returns NISSHI_INVALID_ARGUMENT otherwise.
+ *
+ * A context serves one call at a time: its workspace is the call's.  The *_dev
+ * entry points may be given any stream, and with totals == NULL they return
+ * while their kernels are queued; the next call on the context is then ordered
+ * behind that work on the device, also when it is given another stream (an event
+ * the earlier call left is waited for by the later call's stream), and a call that
+ * has to grow the workspace waits for the device first.  Calls on one context from
+ * several threads must be serialised by the caller; use a context a thread (or
+ * a nisshi_hip_pool) to decode concurrently. */
 int nisshi_hip_decode_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
                           const uint64_t *d_batch_off, uint32_t n_batches, int by_value,
                           const nisshi_columns *d_cols, uint64_t rec_cap, uint64_t hdr_cap,
@@ -187,7 +202,7 @@ int nisshi_hip_decode_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t b
  * that forbid it.  It has no counterpart in the reference.  Same arguments and
  * results as nisshi_hip_decode_dev (whose kernels it shares), but the workspace
  * (per-batch work arrays, the residues of CRC work items, the call's totals) is a
- * fixed array in the library's device image, 986 880 bytes, which every GPU the
+ * fixed array in the library's device image, 1 380 096 bytes, which every GPU the
  * library runs on holds until the process ends, instead of buffers the context
  * grows with hipMalloc.  The call itself makes no hipMalloc, hipFree or other
  * allocating call, and records no profiling events.  A call of more than
@@ -219,8 +234,9 @@ int nisshi_hip_encode_dev(nisshi_hip_ctx *ctx, const nisshi_columns *d_cols, uin
  * rec_cap / hdr_cap.  A large blob is decoded in slices of whole batches (64 MiB,
  * or NISSHI_SLICE_BYTES in the environment when the context is created; 16 at
  * most) so that the copies of one slice overlap the kernels of another; the
- * result is that of one call, except that header slots left unused at the end of
- * a slice stay unused.  The overlap needs page-locked buffers (below). */
+ * records are those of one call, and a slice's header slots (the expected ones,
+ * then those of its batches with more headers) follow those of the slice before
+ * it.  The overlap needs page-locked buffers (below). */
 int nisshi_hip_decode(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
                       const uint64_t *batch_off, uint32_t n_batches, int by_value,
                       const nisshi_columns *cols, uint64_t rec_cap, uint64_t hdr_cap,

@@ -262,7 +262,7 @@ impl Codec {
         // a record is at least seven bytes, a header at least two (header.rs:31-41)
         let most = blob.len() as u64 / 7 + 1;
         let rec_cap = record_counts.map_or(most, |c| c.min(most));
-        let hdr_cap = blob.len() as u64 + 4096 * n as u64 + 1;
+        let hdr_cap = blob.len() as u64 + 1; // covers every call: see nisshi_hip_decode_dev in nisshi_hip.h
         let mut cols = HostColumns::with_capacity(n, rec_cap as usize, hdr_cap as usize);
         let mut totals = Totals::default();
         let c = cols.as_ffi();

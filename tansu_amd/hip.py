@@ -507,22 +507,44 @@ class Codec:
             len(batch_off) - 1, int(by_value), ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(totals)))
         return totals
 
+    @staticmethod
+    def _record_slots(arr: np.ndarray, off: np.ndarray) -> int:
+        """Record slots a decode of these batches can use: the sum of the record counts
+        the headers claim, which the bytes bound (a record is at least seven bytes)."""
+        starts = off[:-1].astype(np.int64)
+        whole = starts[(off[1:].astype(np.int64) - starts) >= 61]
+        claimed = 0
+        if len(whole):
+            b = arr[(whole[:, None] + np.arange(57, 61)).ravel()].reshape(-1, 4).astype(np.int64)
+            claimed = int(((b[:, 0] << 24) | (b[:, 1] << 16) | (b[:, 2] << 8) | b[:, 3]).sum())
+        return min(claimed, len(arr) // 7) + 1
+
     def decode(self, blob: bytes, batch_off, by_value: bool = True, rec_cap: Optional[int] = None,
                hdr_cap: Optional[int] = None):
-        """Decode host bytes; returns (cols: dict of numpy arrays, totals)."""
+        """Decode host bytes; returns (cols: dict of numpy arrays, totals).  Without
+        caps the record columns are sized from the batch headers, and the header
+        columns start at an eighth of the blob and grow while a batch reports
+        NISSHI_CAPACITY (len(blob) + 1 slots cover every case: see
+        nisshi_hip_decode_dev in include/nisshi_hip.h)."""
         arr = np.frombuffer(bytes(blob), dtype=np.uint8)
         off = np.ascontiguousarray(batch_off, dtype=np.uint64)
         n_b = len(off) - 1
-        rec_cap = len(arr) // 7 + 1 if rec_cap is None else rec_cap
-        # header slots: see nisshi_hip_decode_dev in include/nisshi_hip.h
-        hdr_cap = len(arr) + 4096 * n_b + 1 if hdr_cap is None else hdr_cap
-        arrays = C.alloc_device_layout(n_b, rec_cap, hdr_cap)
-        cc = C.as_c(arrays)
-        totals = Totals()
-        self._check(self.lib.nisshi_hip_decode(
-            self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data, n_b,
-            int(by_value), ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(totals)))
-        cols = C.unpack(arrays)
+        rec_cap = self._record_slots(arr, off) if rec_cap is None else rec_cap
+        grow = hdr_cap is None
+        most = len(arr) + 1
+        hdr_cap = min(most, max(len(arr) // 8, 1024)) if grow else hdr_cap
+        while True:
+            arrays = C.alloc_device_layout(n_b, rec_cap, hdr_cap)
+            cc = C.as_c(arrays)
+            totals = Totals()
+            self._check(self.lib.nisshi_hip_decode(
+                self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data, n_b,
+                int(by_value), ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(totals)))
+            cols = C.unpack(arrays)
+            short = grow and hdr_cap < most and totals.n_failed and (cols["status"][:n_b] == C.CAPACITY).any()
+            if not short:
+                break
+            hdr_cap = min(most, max(2 * hdr_cap, int(totals.n_headers)))
         return C.trim(cols, n_b, min(totals.n_records, rec_cap), min(totals.n_headers, hdr_cap)), totals
 
     def encode(self, cols: dict, src: bytes, src_data_off, out_cap: Optional[int] = None):
@@ -552,8 +574,8 @@ class Codec:
         off = np.ascontiguousarray(batch_off, dtype=np.uint64)
         hi = np.ascontiguousarray(high, dtype=np.int64)
         n_b = len(off) - 1
-        rec_cap = len(arr) // 7 + 1 if rec_cap is None else rec_cap
-        hdr_cap = len(arr) + 4096 * n_b + 1 if hdr_cap is None else hdr_cap
+        rec_cap = self._record_slots(arr, off) if rec_cap is None else rec_cap
+        hdr_cap = len(arr) + 1 if hdr_cap is None else hdr_cap   # covers every case: see nisshi_hip_decode_dev
         arrays = C.alloc_device_layout(n_b, rec_cap, hdr_cap)
         cc = C.as_c(arrays)
         counts = (n_b, rec_cap, hdr_cap)

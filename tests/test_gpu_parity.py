@@ -635,3 +635,18 @@ def test_records_of_many_shapes_in_one_batch(codec, seed):
     out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=codec.device)
     t = codec.encode_dev(cols, n_b, d_blob, cols.t["data_off"], out, len(blob), out_off)
     assert out[:t.out_bytes].cpu().numpy().tobytes() == blob.tobytes()
+    # where headers go does not depend on the order the batches decode in: two decodes
+    # into zeroed columns give the same columns byte for byte, and every header slot set
+    # aside is a batch's expected run or the run of a batch that needed more
+    twice = []
+    for _ in range(2):
+        fresh = hip.DeviceColumns(n_b, cols.rec_cap, cols.hdr_cap, codec.device)
+        for t_ in fresh.t.values():
+            t_.zero_()
+        tot = codec.decode_dev(d_blob, len(blob), d_off, n_b, fresh)
+        twice.append((fresh.to_host(), tot))
+    (g1, t1), (g2, t2) = twice
+    assert (t1.n_records, t1.n_headers) == (t2.n_records, t2.n_headers) == (totals.n_records, totals.n_headers)
+    for name in g1:
+        assert g1[name].tobytes() == g2[name].tobytes(), name
+    assert int(g["hdr_count"][:n_b].sum()) <= totals.n_headers <= len(blob) + 1
