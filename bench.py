@@ -30,14 +30,33 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # Which input bytes and which columns each decode kernel is responsible for, as
 # a fraction of the algorithmic bytes of a decode:
 #   in_bytes + 64 * n_batches + 41 * n_records + 16 * n_headers
+# `chunk_share`: the fraction of the input in batches taken chunk by chunk
+# (chunk_kernel); `chunk_walks`: whether that kernel also decodes their records
+# (batches of small records) or only takes their CRC.
+def _walk_bytes(s, share):
+    return share * (s["in_bytes"] + 41 * s["n_records"] + 16 * s["n_headers"])
+
+
 KERNEL_BYTES = {
-    "crc_chunks_kernel": lambda s: s["in_bytes"],
-    "walk_kernel": lambda s: s["in_bytes"] + 41 * s["n_records"],
-    "headers_kernel": lambda s: 16 * s["n_headers"],
     "batch_header_kernel": lambda s: 64 * s["n_batches"],
-    "decode_fused_kernel": lambda s: s["in_bytes"] + 41 * s["n_records"] + 16 * s["n_headers"],
-    "slow_walk_kernel": lambda s: s["in_bytes"] + 41 * s["n_records"] + 16 * s["n_headers"],
+    "chunk_kernel": lambda s: _walk_bytes(s, s["chunk_share"]) if s["chunk_walks"] else s["chunk_share"] * s["in_bytes"],
+    "decode_fused_kernel": lambda s: _walk_bytes(s, 1 - s["chunk_share"]) if s["chunk_walks"]
+    else _walk_bytes(s, 1.0) - s["chunk_share"] * s["in_bytes"],
+    "second_pass_kernel": lambda s: 0,
 }
+
+
+def chunk_share(off, n_batches, n_records, in_bytes):
+    """Which part of the input the library takes chunk by chunk, by its rule (batches
+    of 512 KiB and more, of 128 KiB and more in calls of fewer than 6144 batches;
+    the records with them when a record is small, here by the mean record)."""
+    lens = np.diff(np.asarray(off, dtype=np.int64))
+    chunks = (lens - 21 + 15 + 65535) // 65536
+    big = chunks >= (2 if n_batches < 6144 else 8)
+    walks = n_records > 0 and in_bytes / max(n_records, 1) <= 1024
+    if not walks:
+        big = chunks >= 8
+    return float(lens[big].sum()) / max(in_bytes, 1), bool(walks)
 
 
 def main():
@@ -70,6 +89,26 @@ def main():
 
     # ---- this rank's shard: its own topic-partitions, same shape, own seed
     shape, blob, off, n_records, n_headers, n_batches = shard.make_shard(args.workload, args.scale, rank, world)
+    host_split = None
+    if args.workload == "c5":
+        # C5 arrives as produce requests: the batches wrapped as ProduceRequest v11
+        # partition data, found again on the host (one call over all records fields:
+        # prefix decode and frame split) before the buffer goes to the device as it is
+        import ctypes
+        from tansu_amd import synth
+        blob, field_pos, want_off = synth.make_produce_requests(blob, off, 7000 + rank)
+        got_off = np.zeros(n_batches + 2, dtype=np.uint64)
+        n_found = ctypes.c_uint64(0)
+        lib = hip.load()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            st = lib.nisshi_records_fields_split(blob.ctypes.data, len(blob), field_pos.ctypes.data, len(field_pos), 1,
+                                                 got_off.ctypes.data, len(got_off), None, ctypes.byref(n_found))
+        host_split = {"ms": (time.perf_counter() - t0) / reps * 1e3, "records_fields": len(field_pos),
+                      "what": "nisshi_records_fields_split over the request buffer, one host core"}
+        assert st == 0 and n_found.value == n_batches and (got_off[:n_batches + 1] == want_off).all()
+        off = got_off[:n_batches + 1].copy()
     in_bytes = len(blob)
     d_blob, d_off = codec.to_device(blob, off)
     cols = hip.DeviceColumns(n_batches, n_records, max(n_headers, 1), dev)
@@ -99,7 +138,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    stats = dict(in_bytes=in_bytes, n_batches=n_batches, n_records=n_records, n_headers=n_headers)
+    share, walks = chunk_share(off, n_batches, n_records, in_bytes)
+    stats = dict(in_bytes=in_bytes, n_batches=n_batches, n_records=n_records, n_headers=n_headers,
+                 chunk_share=share, chunk_walks=walks)
     step_ms = elapsed / args.steps * 1e3
     total_records = n_records * world
     algo_bytes = C.algorithmic_decode_bytes(n_batches, n_records, n_headers, in_bytes)
@@ -141,7 +182,8 @@ def main():
                                 "16 B keys, 2 headers, 1k records/batch",
                          "c3": "C3: large values, 1 MiB values, 4 records/batch",
                          "c4": "C4: mixed topic-partitions (five shapes by p mod 5, 64 batches each), 128 a GPU",
-                         "c5": "C5: ragged batches, 1-10k records of 100 B"}[args.workload],
+                         "c5": "C5: ragged batches, 1-10k records of 100 B, as ProduceRequest v11 partition data "
+                               "(1-8 partitions a request, 1-4 batches a records field)"}[args.workload],
             "batches_per_gpu": n_batches,
             "records_per_gpu": n_records,
             "input_bytes_per_gpu": in_bytes,
@@ -163,13 +205,22 @@ def main():
         },
         "kernels_ms": {k: v[0] / v[1] for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
     }
+    if host_split:
+        result["host_split"] = host_split
 
     # ---- the re-encode leg (deflated::Batch::try_from(inflated::Batch)), outside the
     # timed region: columns + payload -> wire bytes, which must equal the input
     out = torch.zeros(in_bytes + 64, dtype=torch.uint8, device=dev)
     out_off = torch.zeros(n_batches + 1, dtype=torch.int64, device=dev)
     te = codec.encode_dev(cols, n_batches, d_blob, cols.t["data_off"], out, in_bytes, out_off)
-    exact = te.out_bytes == in_bytes and bool(torch.equal(out[:in_bytes], d_blob[:in_bytes]))
+    if host_split is None:
+        exact = te.out_bytes == in_bytes and bool(torch.equal(out[:in_bytes], d_blob[:in_bytes]))
+    else:
+        # the batches as they lie in the request buffer, without what is between them
+        lens = cols.t["batch_length"][:n_batches].long() + 12
+        src_idx = torch.repeat_interleave(d_off[:n_batches].long() - (torch.cumsum(lens, 0) - lens), lens) + \
+            torch.arange(int(lens.sum()), device=dev)
+        exact = te.out_bytes == int(lens.sum()) and bool(torch.equal(out[:te.out_bytes], d_blob[src_idx]))
     codec.profile(True)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -224,6 +275,13 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(blob, off, n_batches, n_records)
+        if args.workload != "c1":
+            # C1 is the configuration the reference's own benchmark runs on a CPU: the same two
+            # decodes on a sample of it, one core, beside this workload's
+            from tansu_amd import synth
+            c1_blob, c1_off, c1_nr, _ = synth.make_batches(*synth.config("c1", 0.05))
+            result["cpu_baseline_c1"] = cpu_baseline(c1_blob, c1_off, len(c1_off) - 1, c1_nr, budget_s=4.0,
+                                                     all_cores=False)
 
     print(json.dumps(result))
     if world > 1:
@@ -245,11 +303,14 @@ def device_copy_gbs(dev, n_bytes=1 << 30, reps=10):
     return 2 * n_bytes * reps / (t0.elapsed_time(t1) * 1e-3) / 1e9
 
 
-def cpu_baseline(blob, off, n_batches, n_records, budget_s=20.0):
+def cpu_baseline(blob, off, n_batches, n_records, budget_s=12.0, all_cores=True):
     """The CPU restatement (oracle/, a port of the reference's algorithm) decoding
     a bounded sample of the same workload on one host core: the first batches of
     the workload, as many as fit the time budget, decoded repeatedly when the
-    whole workload takes less than that."""
+    whole workload takes less than that.  `value` is the faithful form (CRC-32C,
+    the reference's Vec<Record> with a Vec<Header> a record, then the columns);
+    `lean` is the same decode straight into the columns, with no allocation a record:
+    not the reference's way, but what a CPU decoder built for this output could do."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     probe = max(1, min(n_batches, 8))
@@ -259,13 +320,17 @@ def cpu_baseline(blob, off, n_batches, n_records, budget_s=20.0):
     sample = int(max(probe, min(n_batches, budget_s / per_batch)))
     sub = blob[:int(off[sample])]
     reps = int(max(1, min(64, budget_s / (per_batch * sample))))
-    total_records = 0
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        st, cols, nr, nh = oracle.decode_columns(sub, off[:sample + 1])
-        assert st == 0 and (cols["status"] == 0).all()
-        total_records += nr
-    dt = time.perf_counter() - t0
+
+    def timed(lean):
+        total = 0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            st, cols, nr, nh = oracle.decode_columns(sub, off[:sample + 1], lean=lean)
+            assert st == 0 and (cols["status"] == 0).all()
+            total += nr
+        return total, nr, time.perf_counter() - t0
+    total_records, nr, dt = timed(False)
+    lean_records, _, lean_dt = timed(True)
     result = {
         "value": total_records / dt,
         "unit": "records/s",
@@ -275,7 +340,13 @@ def cpu_baseline(blob, off, n_batches, n_records, budget_s=20.0):
                   f"in {dt:.2f} s; C restatement of nisshi-sans-io (oracle/): CRC-32C, Vec<Record>-style "
                   "decode, then columns",
         "input_gbs": len(sub) * reps / dt / 1e9,
+        "lean": {"value": lean_records / lean_dt, "unit": "records/s", "cores": 1,
+                 "sample": f"the same sample decoded {reps}x in {lean_dt:.2f} s straight into the columns "
+                           "(no Vec<Record>; same checks, same outcome)",
+                 "input_gbs": len(sub) * reps / lean_dt / 1e9},
     }
+    if not all_cores:
+        return result
     # the same sample on the host cores this GPU's share of the box has (one
     # thread a core, each decoding its own run of batches; the C code runs
     # outside the interpreter lock)

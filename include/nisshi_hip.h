@@ -151,6 +151,20 @@ int nisshi_frame_split(const uint8_t *blob, uint64_t len, uint64_t *batch_off, u
 int nisshi_records_prefix_decode(const uint8_t *buf, uint64_t len, int flexible, uint64_t *pos,
                                  uint32_t *records_len, int *is_null);
 uint64_t nisshi_records_prefix_encode(uint32_t records_len, int flexible, uint8_t *out);
+/* The records fields of one receive buffer in one call (a produce request holds one
+ * a partition: nisshi-sans-io/src/de.rs:701-720 reads the prefix, de.rs:1056-1093
+ * the batches).  field_pos[i]: where field i's length prefix starts in buf, which
+ * the request parser knows as it walks the request.  Decodes each prefix, splits
+ * each field (nisshi_frame_split) and writes the starts of all batches, field after
+ * field, as offsets into buf: batch_off gets *n_batches + 1 entries (cap is its
+ * size), the last one the end of the last field with batches.  first_batch (or NULL;
+ * n_fields + 1 entries): the index of each field's first batch; a null or empty
+ * field has none.  buf and batch_off can go to nisshi_hip_decode as they are: the
+ * extent of a field's last batch then runs on to the first batch of the next
+ * field, and what lies behind a batch's batch_length is never looked at. */
+int nisshi_records_fields_split(const uint8_t *buf, uint64_t len, const uint64_t *field_pos, uint32_t n_fields,
+                                int flexible, uint64_t *batch_off, uint64_t cap, uint32_t *first_batch,
+                                uint64_t *n_batches);
 
 /* Sum of record_count over the batches whose header is well formed and
  * uncompressed: the record capacity a decode of this blob needs.  Device

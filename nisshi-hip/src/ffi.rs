@@ -154,6 +154,7 @@ extern "C" {
     pub fn nisshi_frame_split(blob: *const u8, len: u64, batch_off: *mut u64, cap: u64, n_batches: *mut u64) -> c_int;
     pub fn nisshi_records_prefix_decode(buf: *const u8, len: u64, flexible: c_int, pos: *mut u64, records_len: *mut u32, is_null: *mut c_int) -> c_int;
     pub fn nisshi_records_prefix_encode(records_len: u32, flexible: c_int, out: *mut u8) -> u64;
+    pub fn nisshi_records_fields_split(buf: *const u8, len: u64, field_pos: *const u64, n_fields: u32, flexible: c_int, batch_off: *mut u64, cap: u64, first_batch: *mut u32, n_batches: *mut u64) -> c_int;
     pub fn nisshi_hip_count_dev(ctx: *mut Ctx, d_blob: *const u8, blob_len: u64, d_batch_off: *const u64, n_batches: u32, n_records: *mut u64, stream: *mut c_void) -> c_int;
     pub fn nisshi_hip_decode_dev(ctx: *mut Ctx, d_blob: *const u8, blob_len: u64, d_batch_off: *const u64, n_batches: u32, by_value: c_int, d_cols: *const Columns, rec_cap: u64, hdr_cap: u64, totals: *mut Totals, stream: *mut c_void) -> c_int;
     pub fn nisshi_hip_decode_dev_static(ctx: *mut Ctx, d_blob: *const u8, blob_len: u64, d_batch_off: *const u64, n_batches: u32, by_value: c_int, d_cols: *const Columns, rec_cap: u64, hdr_cap: u64, totals: *mut Totals, stream: *mut c_void) -> c_int;

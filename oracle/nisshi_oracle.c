@@ -619,6 +619,106 @@ int no_decode_columns(const uint8_t *blob, const uint64_t *batch_off, size_t n_b
     return NO_OK;
 }
 
+/* The same columns without the reference's intermediate Vec<Record>: every field
+ * goes from the wire straight into its column, no allocation a record or a header.
+ * Not how the reference works: what a CPU decoder built for this output could do,
+ * timed beside the faithful form as a second baseline.  Same checks in the same
+ * order as no_record_decode, so the same outcome for every input (tests compare
+ * the two). */
+int no_decode_columns_lean(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches,
+                           int by_value, no_columns *c, size_t rec_cap, size_t hdr_cap,
+                           size_t *n_records, size_t *n_headers) {
+    size_t nr = 0, nh = 0;
+    for (size_t b = 0; b < n_batches; b++) {
+        const uint8_t *buf = blob + batch_off[b];
+        size_t len = (size_t)(batch_off[b + 1] - batch_off[b]);
+        no_deflated_batch d;
+        int st = no_deflated_parse(buf, len, &d);
+        c->base_offset[b] = d.base_offset;
+        c->batch_length[b] = d.batch_length;
+        c->partition_leader_epoch[b] = d.partition_leader_epoch;
+        c->magic[b] = d.magic;
+        c->crc[b] = d.crc;
+        c->attributes[b] = d.attributes;
+        c->last_offset_delta[b] = d.last_offset_delta;
+        c->base_timestamp[b] = d.base_timestamp;
+        c->max_timestamp[b] = d.max_timestamp;
+        c->producer_id[b] = d.producer_id;
+        c->producer_epoch[b] = d.producer_epoch;
+        c->base_sequence[b] = d.base_sequence;
+        c->record_count[b] = d.record_count;
+        c->crc_computed[b] = d.crc_computed;
+        c->data_off[b] = batch_off[b] + 61;
+        c->data_len[b] = (uint32_t)d.record_data_len;
+        c->rec_base[b] = (uint32_t)nr;
+        c->hdr_base[b] = (uint32_t)nh;
+        c->hdr_count[b] = 0;
+        int codec = 0;
+        if (st == NO_OK && by_value) {
+            int16_t cleared;
+            st = no_attributes_clear_compression(d.attributes, &cleared);
+            if (st == NO_OK) {
+                no_compression(d.attributes, &codec);
+                if (codec == 0) c->attributes[b] = cleared;
+            }
+        }
+        if (st == NO_OK) st = no_compression(d.attributes, &codec);
+        if (st == NO_OK && codec != 0) st = NO_COMPRESSED;
+        size_t r0 = nr, h0 = nh, pos = 0;
+        const uint8_t *data = d.record_data;
+        size_t dl = d.record_data_len;
+        for (uint32_t i = 0; st == NO_OK && i < d.record_count; i++) {
+            int32_t length, od, count;
+            int64_t ts;
+            no_octets key, value;
+            if ((st = no_varint_decode(data, dl, &pos, &length))) break;
+            if (pos >= dl) { st = NO_PANIC; break; }
+            uint8_t attributes = data[pos++];
+            if ((st = no_varlong_decode(data, dl, &pos, &ts))) break;
+            if ((st = no_varint_decode(data, dl, &pos, &od))) break;
+            if ((st = octets_decode(data, dl, &pos, &key))) break;
+            if ((st = octets_decode(data, dl, &pos, &value))) break;
+            if ((st = no_varint_decode(data, dl, &pos, &count))) break;
+            if (count < 0) { st = NO_PANIC; break; }
+            size_t hfirst = nh;
+            for (int32_t j = 0; j < count; j++) {
+                no_octets hk, hv;
+                if ((st = octets_decode(data, dl, &pos, &hk))) break;
+                if ((st = octets_decode(data, dl, &pos, &hv))) break;
+                if (nh >= hdr_cap) return NO_CAPACITY;
+                c->hkey_len[nh] = (int32_t)hk.len;
+                c->hval_len[nh] = (int32_t)hv.len;
+                c->hkey_off[nh] = (uint32_t)(hk.ptr - data);
+                c->hval_off[nh] = (uint32_t)(hv.ptr - data);
+                nh++;
+            }
+            if (st) break;
+            if (nr >= rec_cap) return NO_CAPACITY;
+            c->length[nr] = length;
+            c->rattributes[nr] = attributes;
+            c->timestamp_delta[nr] = ts;
+            c->offset_delta[nr] = od;
+            c->key_len[nr] = (int32_t)key.len;
+            c->val_len[nr] = (int32_t)value.len;
+            c->key_off[nr] = (uint32_t)(key.ptr - data);
+            c->val_off[nr] = (uint32_t)(value.ptr - data);
+            c->rhdr_base[nr] = (uint32_t)hfirst;
+            c->rhdr_count[nr] = count;
+            nr++;
+        }
+        c->status[b] = st;
+        if (st != NO_OK) { /* a failed batch leaves no records */
+            nr = r0;
+            nh = h0;
+            continue;
+        }
+        c->hdr_count[b] = (uint32_t)(nh - h0);
+    }
+    *n_records = nr;
+    *n_headers = nh;
+    return NO_OK;
+}
+
 static no_record *records_from_columns(const no_columns *c, size_t b, const uint8_t *base) {
     size_t n = c->record_count[b];
     no_record *recs = (no_record *)calloc(n ? n : 1, sizeof(no_record));

@@ -198,6 +198,10 @@ typedef struct {
 int no_decode_columns(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches,
                       int by_value, no_columns *cols, size_t rec_cap, size_t hdr_cap,
                       size_t *n_records, size_t *n_headers);
+/* the same outcome without the intermediate Vec<Record> (see the definition) */
+int no_decode_columns_lean(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches,
+                      int by_value, no_columns *cols, size_t rec_cap, size_t hdr_cap,
+                      size_t *n_records, size_t *n_headers);
 
 /* Re-encode batches from columns (deflated::Batch::try_from(inflated::Batch) over a
  * whole frame, deflated.rs:52-63).  Payload spans are read from src at

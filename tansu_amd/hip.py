@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libn
 EXPORTS = [
     "nisshi_hip_ctx_create", "nisshi_hip_ctx_destroy", "nisshi_hip_status_str",
     "nisshi_hip_last_error", "nisshi_frame_split", "nisshi_records_prefix_decode",
-    "nisshi_records_prefix_encode", "nisshi_hip_count_dev", "nisshi_hip_decode_dev",
+    "nisshi_records_prefix_encode", "nisshi_records_fields_split", "nisshi_hip_count_dev", "nisshi_hip_decode_dev",
     "nisshi_hip_decode_dev_static",
     "nisshi_hip_encode_dev", "nisshi_hip_decode", "nisshi_hip_encode", "nisshi_hip_crc32c_dev",
     "nisshi_hip_profile_enable", "nisshi_hip_profile_get", "nisshi_hip_profile_name",
@@ -125,6 +125,7 @@ def load() -> ctypes.CDLL:
                                                  ctypes.POINTER(u32), ctypes.POINTER(i32)]
     lib.nisshi_records_prefix_encode.argtypes = [u32, i32, vp]
     lib.nisshi_records_prefix_encode.restype = u64
+    lib.nisshi_records_fields_split.argtypes = [vp, u64, vp, u32, i32, vp, u64, vp, ctypes.POINTER(u64)]
     lib.nisshi_hip_count_dev.argtypes = [vp, vp, u64, vp, u32, ctypes.POINTER(u64), vp]
     lib.nisshi_hip_decode_dev.argtypes = [vp, vp, u64, vp, u32, i32, ctypes.POINTER(C.CColumns),
                                           u64, u64, ctypes.POINTER(Totals), vp]
@@ -183,6 +184,23 @@ def frame_split(blob: bytes) -> np.ndarray:
     if st:
         raise NisshiError(st)
     return off[:n.value + 1].copy()
+
+
+def records_fields_split(buf, field_pos, flexible: bool = True, cap: Optional[int] = None):
+    """The batches of all records fields of one receive buffer (host side):
+    (batch_off np.uint64[n + 1] into buf, first_batch np.uint32[n_fields + 1])."""
+    lib = load()
+    arr = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+    pos = np.ascontiguousarray(field_pos, dtype=np.uint64)
+    cap = len(arr) // 61 + 2 if cap is None else cap
+    off = np.zeros(cap, dtype=np.uint64)
+    first = np.zeros(len(pos) + 1, dtype=np.uint32)
+    n = ctypes.c_uint64(0)
+    st = lib.nisshi_records_fields_split(arr.ctypes.data, len(arr), pos.ctypes.data if len(pos) else None, len(pos),
+                                         int(flexible), off.ctypes.data, cap, first.ctypes.data, ctypes.byref(n))
+    if st:
+        raise NisshiError(st)
+    return off[:n.value + 1].copy(), first
 
 
 _TORCH_BY_SIZE = None

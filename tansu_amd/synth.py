@@ -294,3 +294,50 @@ def mixed_partitions(n_partitions: int, batches_each: int, seed: int = SEED_BASE
         shape, r = kinds[p % 5]
         out.append(make_batches(shape, np.full(batches_each, r), seed + 1000 * p))
     return out
+
+
+def uvarint(v: int) -> bytes:
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7f) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def make_produce_requests(blob: np.ndarray, batch_off: np.ndarray, seed: int, max_partitions: int = 8,
+                          max_batches: int = 4):
+    """The batches of `blob` as they arrive on the wire: ProduceRequest v11 partition
+    data, one after the other (requests of 1..max_partitions partitions; a partition's
+    data is its index, i32, then the records field, a flexible prefix uvarint(len + 1)
+    and 1..max_batches batches, then an empty tagged-field section: message
+    ProduceRequest, PartitionProduceData, of the Kafka protocol).  Returns (buf,
+    field_pos, batch_off): the buffer, where each records field's prefix starts, and
+    the starts of the batches in buf with the end of the last field as last entry."""
+    n = len(batch_off) - 1
+    draws = splitmix64(seed, 2 * n + 2)
+    parts = []
+    field_pos, new_off = [], []
+    at, b, i = 0, 0, 0
+    while b < n:
+        in_request = 1 + int(draws[2 * i] % max_partitions)
+        for p in range(in_request):
+            if b >= n:
+                break
+            take = min(1 + int(draws[2 * i + 1] % max_batches), n - b)
+            i += 1
+            lo, hi = int(batch_off[b]), int(batch_off[b + take])
+            head = int(p).to_bytes(4, "big")
+            prefix = uvarint(hi - lo + 1)
+            field_pos.append(at + len(head))
+            start = at + len(head) + len(prefix)
+            new_off.extend(start + int(batch_off[b + j]) - lo for j in range(take))
+            parts.append(head + prefix)
+            parts.append(blob[lo:hi].tobytes())
+            parts.append(b"\x00")
+            at = start + (hi - lo) + 1
+            b += take
+        i += 1
+    new_off.append(at - 1)   # the end of the last field
+    buf = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    return buf, np.asarray(field_pos, dtype=np.uint64), np.asarray(new_off, dtype=np.uint64)

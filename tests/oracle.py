@@ -70,6 +70,7 @@ def _load():
     lib.no_decode_columns.argtypes = [ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_int,
                                       ctypes.POINTER(FieldColumns), sz, sz,
                                       ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.no_decode_columns_lean.argtypes = lib.no_decode_columns.argtypes
     lib.no_encode_columns.argtypes = [ctypes.POINTER(FieldColumns), sz, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_void_p]
     lib.no_builder_columns.argtypes = [ctypes.POINTER(FieldColumns), sz, ctypes.c_void_p,
@@ -127,8 +128,9 @@ def frame_split(blob: bytes):
     return st, off[:n.value + 1].copy()
 
 
-def decode_columns(blob, batch_off, by_value=True, rec_cap=None, hdr_cap=None):
-    """Decode a blob of batches.  Returns (status, cols, n_records, n_headers)."""
+def decode_columns(blob, batch_off, by_value=True, rec_cap=None, hdr_cap=None, lean=False):
+    """Decode a blob of batches.  Returns (status, cols, n_records, n_headers).
+    `lean`: by the variant that fills the columns without the intermediate Vec<Record>."""
     blob = np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
     batch_off = np.ascontiguousarray(batch_off, dtype=np.uint64)
     n_b = len(batch_off) - 1
@@ -139,9 +141,9 @@ def decode_columns(blob, batch_off, by_value=True, rec_cap=None, hdr_cap=None):
     cols = C.alloc_host(n_b, rec_cap, hdr_cap)
     cc = as_c(cols)
     nr, nh = ctypes.c_size_t(0), ctypes.c_size_t(0)
-    st = LIB.no_decode_columns(blob.ctypes.data, batch_off.ctypes.data, n_b, int(by_value),
-                               ctypes.byref(cc), rec_cap, hdr_cap, ctypes.byref(nr),
-                               ctypes.byref(nh))
+    fn = LIB.no_decode_columns_lean if lean else LIB.no_decode_columns
+    st = fn(blob.ctypes.data, batch_off.ctypes.data, n_b, int(by_value), ctypes.byref(cc), rec_cap, hdr_cap,
+            ctypes.byref(nr), ctypes.byref(nh))
     return st, C.trim(cols, n_b, nr.value, nh.value), nr.value, nh.value
 
 

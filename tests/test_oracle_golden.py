@@ -300,3 +300,34 @@ def test_builder_length_quirk():
         wire_bl = struct.unpack_from(">i", out, 8)[0]
         assert wire_bl - int(bl[0]) == short_by
         assert struct.unpack_from(">I", out, 17)[0] == int(crc[0])
+
+
+def test_lean_decode_gives_the_faithful_decode():
+    """The decode that fills the columns without the intermediate Vec<Record> (the
+    second CPU baseline of bench.py) against the restatement of the reference's:
+    golden frames, a seeded workload with headers, and that workload with bytes
+    changed at random (batches that fail keep their status and leave no records)."""
+    import numpy as np
+    from tansu_amd import synth
+    from util import find_batches, load_vectors, offsets_of
+    blobs = []
+    for case in load_vectors()["decode_frames"]:
+        frame = bytes(case["frame"])
+        batches = [frame[a:b] for a, b in find_batches(frame)]
+        blobs.append((np.frombuffer(b"".join(batches), dtype=np.uint8), offsets_of(batches)))
+    shape, counts, seed = synth.config("c2", 0.002)
+    blob, off, nr, nh = synth.make_batches(shape, counts, seed)
+    blobs.append((blob, off))
+    rng = np.random.default_rng(9)
+    for _ in range(30):
+        bad = blob.copy()
+        for at in rng.integers(0, len(bad), 40):
+            bad[at] = rng.integers(0, 256)
+        blobs.append((bad, off))
+    for data, offs in blobs:
+        for by_value in (True, False):
+            st1, a, nr1, nh1 = oracle.decode_columns(data, offs, by_value)
+            st2, b, nr2, nh2 = oracle.decode_columns(data, offs, by_value, lean=True)
+            assert (st1, nr1, nh1) == (st2, nr2, nh2)
+            for name in a:
+                assert (a[name] == b[name]).all(), name

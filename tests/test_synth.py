@@ -64,3 +64,35 @@ def test_mixed_shard_is_a_gpus_share():
     per_batch = cols["record_count"].reshape(10, 64)
     assert (per_batch == per_batch[:, :1]).all()
     assert per_batch[:, 0].tolist()[:5] == [1000, 1, 4, 100, 1]
+
+
+def test_produce_requests_split_back_into_their_batches():
+    """Batches wrapped as ProduceRequest v11 partition data (index, flexible records
+    prefix, batches, tagged fields) and split on the host in one call: the starts are
+    those the generator placed, and the oracle decodes the buffer with them as it
+    decodes the plain blob (what lies between a batch's end and the next batch's
+    start, the next field's index and prefix, is not looked at)."""
+    from tansu_amd import hip
+    shape, counts, seed = synth.config("c5", 0.004)
+    blob, off, nr, nh = synth.make_batches(shape, counts, seed)
+    buf, field_pos, want_off = synth.make_produce_requests(blob, off, seed + 1)
+    assert 1 <= len(field_pos) <= len(counts) and len(buf) > len(blob)
+    got_off, first = hip.records_fields_split(buf, field_pos, flexible=True)
+    assert (got_off == want_off).all()
+    assert first[0] == 0 and first[-1] == len(counts) and (np.diff(first.astype(np.int64)) >= 1).all()
+    st, plain, nr1, nh1 = oracle.decode_columns(blob, off)
+    st2, framed, nr2, nh2 = oracle.decode_columns(buf, got_off)
+    assert st == st2 == 0 and (nr1, nh1) == (nr2, nh2) == (nr, nh)
+    for name in ("status", "record_count", "crc_computed", "data_len"):
+        assert (plain[name] == framed[name]).all(), name
+    assert (framed["data_off"] == got_off[:-1] + 61).all()
+    # a field cut short, and a list too short for the batches
+    import ctypes
+    lib = hip.load()
+    n = ctypes.c_uint64(0)
+    small = np.zeros(4, dtype=np.uint64)
+    assert lib.nisshi_records_fields_split(buf.ctypes.data, len(buf), field_pos.ctypes.data, len(field_pos), 1,
+                                           small.ctypes.data, 4, None, ctypes.byref(n)) == 7   # NISSHI_CAPACITY
+    full = np.zeros(len(counts) + 2, dtype=np.uint64)
+    assert lib.nisshi_records_fields_split(buf.ctypes.data, len(buf) - 100, field_pos.ctypes.data, len(field_pos), 1,
+                                           full.ctypes.data, len(full), None, ctypes.byref(n)) == 1  # NISSHI_TRY_GET
