@@ -83,6 +83,7 @@ def main():
         # the ranks exchange nothing but the barrier around the timed region and the
         # elapsed time: host-side, over gloo (the data path has no collective)
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    local %= max(1, torch.cuda.device_count())  # (more ranks than devices only when rehearsing on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     codec = hip.Codec(local)

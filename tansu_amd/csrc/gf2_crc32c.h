@@ -70,7 +70,8 @@ struct CrcTables {
     uint32_t inv8[kRowBytes];   // x^(-8k): undoes k trailing zero bytes
     uint32_t lane_weight[64];   // x^(128 * (63 - lane)): position of a lane's 16 bytes in the row
     uint32_t pow8[40];          // x^(8 * 2^k)
-    uint32_t chunk_weight;      // x^(8 * kChunkBytes)
+    uint32_t chunk_weight;      // x^(8 * kChunkBytes) = W
+    uint32_t chunk_pow[7];      // W^(2^k), k = 0 .. 6
 };
 
 inline uint32_t host_xpow(uint64_t n) {  // x^n mod P
@@ -97,6 +98,8 @@ inline void build_crc_tables(CrcTables *t) {
         p = gf_mulmod(p, p);
     }
     t->chunk_weight = host_xpow(8ull * kChunkBytes);
+    t->chunk_pow[0] = t->chunk_weight;
+    for (int k = 1; k < 7; k++) t->chunk_pow[k] = gf_mulmod(t->chunk_pow[k - 1], t->chunk_pow[k - 1]);
 }
 
 #if defined(__HIPCC__)

@@ -44,6 +44,7 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 // Internal per-batch flags
 constexpr uint32_t kFlagExact = 1u;   // needs the sequential walk
 constexpr uint32_t kFlagMore = 2u;    // more headers than the slots it was expected to need: walked again
+constexpr uint32_t kFlagChunks = 8u;  // the batch's chunks are work items of chunk_kernel: its CRC comes from their residues
 constexpr uint32_t kFlagSeg = 4u;     // CRC and records chunk by chunk, a wave each (chunk_kernel); decode_fused_kernel checks that the chunks join up
 
 struct Work {
@@ -287,8 +288,8 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
     // large batch of anything else gets its CRC from its chunks and its records
     // from one wave.  Either way its chunks are work items.
     bool segmented = fits && chunks >= seg_chunks && first_size != 0 && first_size <= kSegRecordMax;
-    if (segmented) w.flags[b] |= kFlagSeg;
     chunk_items = segmented || chunks >= kBigChunks ? chunks : 0;
+    if (chunk_items) w.flags[b] |= segmented ? kFlagSeg | kFlagChunks : kFlagChunks;
     w.hdr_need[b] = 0;
     return ((uint64_t)expect << 32) | (fits ? record_count : 0u);
 }
@@ -485,15 +486,13 @@ __device__ inline uint32_t crc_combine_wave(const uint64_t *batch_off, const int
         uint32_t size = done == 0 && (m & 63) ? (m & 63) : 64;
         uint32_t pad = 64 - size;
         uint32_t v = (uint32_t)lane >= pad ? part[done + (uint32_t)lane - pad] : 0;
-        uint32_t wd = t->chunk_weight;
 #pragma unroll 1
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t x = __shfl_up(v, d, 64);
-            if (lane < d) x = 0;
-            v ^= gf_mulmod(x, wd);
-            wd = gf_mulmod(wd, wd);
+        for (int k = 0; k < 6; k++) {
+            uint32_t x = __shfl_up(v, 1u << k, 64);
+            if (lane < (1 << k)) x = 0;
+            v ^= gf_mulmod(x, t->chunk_pow[k]);  // W^(2^k)
         }
-        r = gf_mulmod(r, wd) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 63);  // wd = W^64
+        r = (done ? gf_mulmod(r, t->chunk_pow[6]) : 0u) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 63);  // W^64
         done += size;
     }
     // x^(8 * last_bytes): the product of the table's entries for the bits set, over the lanes
@@ -1839,7 +1838,7 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     // them: its CRC from their residues; and its records are there, if they were
     // decoded chunk by chunk and the chunks join up.  Otherwise the batch is walked
     // here like any other, but for the CRC.
-    bool in_chunks = !seg && (chunks >= kBigChunks || (flags & kFlagSeg));
+    bool in_chunks = !seg && (flags & kFlagChunks);
     bool joined_up = false;
     if (in_chunks) {
         uint32_t first_item = chunk_first(w, b, prefixed != 0, lane);
