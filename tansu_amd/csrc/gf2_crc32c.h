@@ -21,6 +21,7 @@
 // where a table-driven CRC needs one LDS lookup per byte.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace nisshi {
@@ -72,7 +73,16 @@ struct CrcTables {
     uint32_t pow8[40];          // x^(8 * 2^k)
     uint32_t chunk_weight;      // x^(8 * kChunkBytes) = W
     uint32_t chunk_pow[7];      // W^(2^k), k = 0 .. 6
+    // For the residue of an accumulator row (crc_row_residue_staged), 16-byte aligned:
+    // slice[k][v] = v * x^(8 * (k + 1)) for a byte v in the low bits of a word (the
+    // byte-wise CRC tables, "slicing by four": (b0 | b1 << 8 | b2 << 16 | b3 << 24) * x^32
+    // = slice[3][b0] ^ slice[2][b1] ^ slice[1][b2] ^ slice[0][b3]), and
+    // lane_pad_weight[p][l] = lane_weight[l] * inv8[p], a lane's place in the row with p
+    // bytes of padding at the row's end divided out.
+    alignas(16) uint32_t slice[4][256];
+    uint32_t lane_pad_weight[kRowBytes][64];
 };
+static_assert(offsetof(CrcTables, slice) % 16 == 0, "the slice tables are loaded sixteen bytes a lane");
 
 inline uint32_t host_xpow(uint64_t n) {  // x^n mod P
     uint32_t r = kOne, base = kX;
@@ -97,6 +107,15 @@ inline void build_crc_tables(CrcTables *t) {
         t->pow8[k] = p;
         p = gf_mulmod(p, p);
     }
+    for (uint32_t v = 0; v < 256; v++) {
+        uint32_t r = v;
+        for (int k = 0; k < 4; k++) {
+            for (int i = 0; i < 8; i++) r = gf_mulx(r);
+            t->slice[k][v] = r;
+        }
+    }
+    for (int p = 0; p < kRowBytes; p++)
+        for (int l = 0; l < 64; l++) t->lane_pad_weight[p][l] = gf_mulmod(t->lane_weight[l], t->inv8[p]);
     t->chunk_weight = host_xpow(8ull * kChunkBytes);
     t->chunk_pow[0] = t->chunk_weight;
     for (int k = 1; k < 7; k++) t->chunk_pow[k] = gf_mulmod(t->chunk_pow[k - 1], t->chunk_pow[k - 1]);
@@ -186,6 +205,34 @@ __device__ inline uint32_t crc_row_residue(const uint32_t (&a)[4], int lane, con
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u128;
+
+// crc_row_residue() with `pad` bytes of zero padding at the row's end divided out
+// (pad < kRowBytes, the same in every lane), for a wave that has 4 KiB of LDS to
+// spare (`tab`, 16-byte aligned; whatever it held is gone): a lane's four words are
+// reduced through the byte-wise tables, staged in `tab` first, instead of bit by
+// bit (128 dependent steps of three instructions), and the lane's weight comes
+// with the padding already divided out (a multiplication less).
+__device__ __forceinline__ uint32_t crc_row_residue_staged(const uint32_t (&a)[4], int lane, const CrcTables *t,
+                                                           uint32_t pad, lds_u32 *tab) {
+    typedef __attribute__((address_space(1))) const u32x4 gbl_u128;
+    typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
+    gbl_u128 *src = (gbl_u128 *)(uintptr_t)&t->slice[0][0];
+    u32x4 q0 = src[lane], q1 = src[64 + lane], q2 = src[128 + lane], q3 = src[192 + lane];
+    uint32_t weight = ((gbl_u32 *)(uintptr_t)&t->lane_pad_weight[0][0])[pad * 64 + (uint32_t)lane];
+    lds_u128 *dst = (lds_u128 *)tab;
+    dst[lane] = q0;
+    dst[64 + lane] = q1;
+    dst[128 + lane] = q2;
+    dst[192 + lane] = q3;
+    asm volatile("" ::: "memory");
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        c ^= a[i];
+        c = xor3(tab[768 + (c & 0xffu)], tab[512 + ((c >> 8) & 0xffu)], tab[256 + ((c >> 16) & 0xffu)]) ^ tab[c >> 24];
+    }
+    return wave_xor(gf_mulmod(c, weight));
+}
 
 // Byte mask of a little-endian word at absolute address `addr`: keep the bytes in [lo, hi).
 __device__ __forceinline__ uint32_t byte_mask(uint64_t addr, uint64_t lo, uint64_t hi) {
@@ -453,9 +500,8 @@ struct BatchStream {
     __device__ __forceinline__ uint32_t finish_segment(uint32_t to, const CrcTables *t) {
         to = to < rows ? to : rows;
         if (next_row < to) pull(to);
-        uint32_t r = crc_row_residue(acc, lane, t);
-        if (to == rows) r = gf_mulmod(r, t->inv8[rows * kRowBytes - hi]);
-        return r;
+        // (the rows are through the ring: its first 4 KiB hold the tables from here on)
+        return crc_row_residue_staged(acc, lane, t, to == rows ? rows * kRowBytes - hi : 0u, ring);
     }
 
     // the CRC-32C of [lo, hi)
@@ -463,9 +509,7 @@ struct BatchStream {
         if (!fold) return 0;
         pull(rows);
         if (hi == lo) return 0;
-        uint32_t r = crc_row_residue(acc, lane, t);
-        uint32_t pad = rows * kRowBytes - hi;
-        return ~gf_mulmod(r, t->inv8[pad]);
+        return ~crc_row_residue_staged(acc, lane, t, rows * kRowBytes - hi, ring);
     }
 };
 

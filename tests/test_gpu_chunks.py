@@ -134,9 +134,13 @@ def test_few_and_many_batches_give_the_same_columns(codec):
         other.close()
     finally:
         del os.environ["NISSHI_SEG_FEW_BATCHES"]
+    # (slots past the records and headers decoded are never written)
+    header_level = {f for _, fields in C.HEADER_GROUPS for f in fields}
     for name in g:
-        assert (g[name] == g2[name]).all(), name
+        n = totals.n_headers if name in header_level else len(g[name])
+        assert (g[name][:n] == g2[name][:n]).all(), name
     assert totals.n_records == totals2.n_records == nr
+    assert totals.n_headers == totals2.n_headers == nh
 
 
 def test_batches_of_many_records_are_written_in_pieces(codec):
