@@ -71,6 +71,7 @@ struct Work {
     uint64_t *totals;       // [0] record slots [1] header slots [2] failed [3] exact [4] out bytes [5] chunks
                             // [6] end of the expected header slots [7] entries of `list`
     uint64_t *tile_sum;     // the scans over very many batches: two sums a tile of kScanTile batches
+    uint32_t *shape_guess;  // kShapeWords words a block of kSumBlock batches: the shape of the first record of the block's first batch (guess_shape)
     uint32_t *chunk_done;   // encode: the CRC work item has its residue already (from the copy of a long span)
 };
 
@@ -294,9 +295,18 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
     return ((uint64_t)expect << 32) | (fits ? record_count : 0u);
 }
 
+__device__ inline void guess_shape(const uint8_t *blob, const uint64_t *batch_off, uint32_t n, uint32_t blk, const Work &w);
+
+// The workgroups past the blocks' (one a block, launched when w.shape_guess is
+// there) each leave a guess at the shape of their block's records: guess_shape.
 __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
                                     int by_value, nisshi_columns c, Work w, uint32_t count_small, uint32_t seg_chunks) {
     __shared__ uint64_t wave_sums[kSumBlock >> 6];
+    uint32_t n_blocks = (n + kSumBlock - 1) / kSumBlock;
+    if (blockIdx.x >= n_blocks) {
+        if (threadIdx.x == 0) guess_shape(blob, batch_off, n, blockIdx.x - n_blocks, w);
+        return;
+    }
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     // the call's totals start at zero: their first users are the kernels after this one
     if (b < 8) w.totals[b] = 0;
@@ -790,10 +800,14 @@ struct RingView {
 // attributes byte), 2 offset delta, 3 key, 4 value, 5 header count, then a key
 // and a value per header.  The bytes of every varint belong to the shape, except
 // that of the two deltas only the widths do.
-template <int kRows>
-__device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring, uint32_t at0, uint32_t size) {
-    lds_u128 *htab = tab + kShapeChecks;
-    lds_u128 *out = htab + kShapeHdrs;
+//
+// Tab: where the table goes (LDS, or global memory for a guess handed to other
+// waves); Src: where the record's bytes come from, read64(position).  kGuard: the
+// source may not be read at or past the record's end (global memory).
+template <bool kGuard, class Tab, class Src>
+__device__ __forceinline__ int learn_shape_any(Tab tab, Src &ring, uint32_t at0, uint32_t size) {
+    Tab htab = tab + kShapeChecks;
+    Tab out = htab + kShapeHdrs;
     uint32_t p = 0;  // offset in the record
     uint32_t cur_off = 0, cur_mask = 0, cur_pat = 0, noted = 0;
     uint32_t fields = 6;
@@ -803,6 +817,10 @@ __device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring,
     for (uint32_t i = 0; i < fields && !bad; i++) {
         bool delta = i == 1 || i == 2;
         if (i == 1) p += 1;
+        if (kGuard && p >= size) {
+            bad = true;
+            break;
+        }
         uint64_t w = ring.read64(at0 + p);
         uint32_t used;
         int32_t v;
@@ -861,7 +879,49 @@ __device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring,
     else if (bad || p != size) st = kWalkExact;
     out[0] = u32x4{(noted + 3) & ~3u, n_len, (uint32_t)length, o_od};
     out[1] = u32x4{o_key, o_val, (uint32_t)klen, (uint32_t)vlen};
-    out[2] = u32x4{hc, (uint32_t)st, 0, 0};
+    out[2] = u32x4{hc, (uint32_t)st, size, 0};
+    return st;
+}
+
+template <int kRows>
+__device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring, uint32_t at0, uint32_t size) {
+    learn_shape_any<false>(tab, ring, at0, size);
+}
+
+// A batch's record data in global memory as a source of learn_shape_any.
+struct GlobalBytes {
+    Reader rd;
+    __device__ __forceinline__ uint64_t read64(uint32_t at) { return rd.get64(at); }
+};
+
+// The shape of the first record of the first batch of block `blk`, left in global
+// memory as a first guess for the waves that walk the block's batches: batches that
+// lie side by side mostly come from one producer and share a shape, and a wave that
+// finds its batch's records fitting the guess need not learn the shape itself.  (A
+// guess is only ever tested against records, as a learnt shape is: a wrong or
+// missing guess costs the wave its own learning and nothing else.)  By one lane.
+__device__ inline void guess_shape(const uint8_t *blob, const uint64_t *batch_off, uint32_t n, uint32_t blk, const Work &w) {
+    u32x4 *tab = reinterpret_cast<u32x4 *>(w.shape_guess) + (uint64_t)blk * (kShapeWords / 4);
+    uint32_t b = blk * kSumBlock;
+    int st = kWalkExact;
+    if (b < n) {
+        const uint8_t *p = blob + batch_off[b];
+        uint64_t len = batch_off[b + 1] - batch_off[b];
+        if (len > 61) {
+            int32_t batch_length = (int32_t)be32(p + 8);
+            uint32_t codec = be16(p + 21) & 7u, count = be32(p + 57);
+            if (batch_length > 49 && (uint64_t)batch_length - 49 <= len - 61 && codec == 0 && count &&
+                (uint64_t)count * 7 <= (uint64_t)batch_length - 49) {
+                uint32_t data_len = (uint32_t)batch_length - 49;
+                GlobalBytes src{Reader(p + 61, data_len)};
+                uint32_t used;
+                int32_t length;
+                if (fast_varint(src.read64(0), used, length) && length >= 0 && (uint64_t)used + (uint32_t)length <= data_len)
+                    st = learn_shape_any<true>(tab, src, 0, used + (uint32_t)length);
+            }
+        }
+    }
+    if (st != kWalkDone) tab[kShapeChecks + kShapeHdrs] = u32x4{0, 0, 0, 0};  // no compares: no guess
 }
 
 // The record walk of one batch by the wave that streams it.  Each round pulls
@@ -880,7 +940,7 @@ template <int kRows, bool kFold>
 __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c, uint32_t rec_base, HeaderSlots &slots,
                                              BatchStream<kRows, kFold> &stream, lds_u128 *tab, int lane,
                                              uint32_t *k_out, uint32_t *pos_out, bool seg = false,
-                                             uint32_t pos_end = 0xffffffffu) {
+                                             uint32_t pos_end = 0xffffffffu, bool guessed = false) {
     uint32_t count = uni(c.record_count[b]);
     uint64_t rbase = rec_base;
     uint32_t data_len = uni(c.data_len[b]);
@@ -893,6 +953,22 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     shape.n_checks = 0;
     shape.size = 0;
     shape.hc = 0;
+    if (guessed) {
+        // `tab` holds a shape already (guess_shape's, of a batch nearby): the walk starts
+        // with it in hand as if it had learnt it from a record before
+        const lds_u128 *in4 = htab + kShapeHdrs;
+        u32x4 a = in4[0], b4 = in4[1], c4 = in4[2];
+        shape.n_checks = uni(a.x);
+        shape.size = uni(c4.z);
+        shape.n_len = uni(a.y);
+        shape.length = (int32_t)uni(a.z);
+        shape.o_od = uni(a.w);
+        shape.o_key = uni(b4.x);
+        shape.o_val = uni(b4.y);
+        shape.klen = (int32_t)uni(b4.z);
+        shape.vlen = (int32_t)uni(b4.w);
+        shape.hc = uni(c4.x);
+    }
     // The stores of a round are issued in the next round, after that round's rows
     // have been taken from the look-ahead queue and before the queue is refilled:
     // the wait for the queued loads then never waits for stores just issued, and
@@ -1878,9 +1954,18 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         n_first = n_first < (uint32_t)kAhead ? n_first : (uint32_t)kAhead;
         stream.load(first_rows, n_first);
     }
+    // the guess at the shape of the block's records (guess_shape), on its way while the bases are worked out
+    u32x4 guess = u32x4{0, 0, 0, 0};
+    bool guessed = streamed && w.shape_guess != nullptr;
+    if (guessed && (uint32_t)lane < kShapeWords / 4) {
+        typedef __attribute__((address_space(1))) const u32x4 gbl_u128;
+        guess = ((gbl_u128 *)(uintptr_t)w.shape_guess)[(uint64_t)(b / kSumBlock) * (kShapeWords / 4) + (uint32_t)lane];
+    }
     // where the batch's records and headers go
     uint32_t rec_base, hdr_base;
     batch_bases(w, b, prefixed != 0, before, lane, rec_base, hdr_base);
+    // (the guess was asked for before the sums were: it is here by now)
+    if (guessed && (uint32_t)lane < kShapeWords / 4) ((lds_u128 *)shape_tab)[lane] = guess;
 #ifdef NISSHI_PHASES
     tl[1] = __builtin_readcyclecounter();
 #endif
@@ -1946,7 +2031,8 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     if (do_walk) {
         HeaderSlots slots;
         slots.init(hdr_first, hdr_slots, hdr_cap);
-        int st = walk_streamed(b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane, &k, &pos, seg, pos_end);
+        lds_order();
+        int st = walk_streamed(b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane, &k, &pos, seg, pos_end, guessed);
         if (st == kWalkChain) st = walk_chain(blob, b, c, rec_base, slots, stream, lane, &k, &pos, seg, pos_end);
 #ifdef NISSHI_PHASES
         tl[3] = __builtin_readcyclecounter();
