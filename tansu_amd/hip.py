@@ -315,8 +315,20 @@ class Codec:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- per-kernel timing ----------------------------------------------------
-    def profile(self, on: bool):
-        self._check(self.lib.nisshi_hip_profile_enable(self.ctx, int(on)))
+    def profile(self, on: bool, only: Optional[str] = None):
+        """Per-kernel event marks on or off; `only`: the name of the one decode kernel to time."""
+        mode = int(bool(on))
+        if on and only is not None:
+            k = 0
+            while True:
+                name = self.lib.nisshi_hip_profile_name(k)
+                if name is None:
+                    raise ValueError(f"no kernel named {only}")
+                if name.decode() == only:
+                    break
+                k += 1
+            mode = 2 + k
+        self._check(self.lib.nisshi_hip_profile_enable(self.ctx, mode))
 
     def kernel_times(self) -> dict:
         """{kernel name: (total ms, launches)} since profile(True); waits for the events."""
