@@ -169,6 +169,18 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
             uintptr_t a = a0 + 4 * i <= last ? a0 + 4 * i : last;
             d[i] = *(gbl_u32 *)a;
         }
+        // The first record's head is read below, a few bytes at a time, each read
+        // waiting for the one before: ask for the lines it will touch now, so that
+        // those reads find them in the cache instead of going to memory one after
+        // the other (the values loaded here are not used).
+        uint32_t touch[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            uintptr_t a = a0 + 64 + 64 * i <= last ? a0 + 64 + 64 * i : last;
+            touch[i] = *(gbl_u32 *)a;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) asm volatile("" ::"v"(touch[i]));
 #pragma unroll
         for (int i = 0; i < 16; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], (uint32_t)(at & 3));
         auto b32 = [&](int off) -> uint32_t {  // big-endian 32 bits at a constant byte offset
