@@ -2138,7 +2138,7 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
                                                           uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed,
-                                                          const uint64_t *before) {
+                                                          const uint64_t *before, uint32_t big_from) {
     // kPack waves a workgroup, each with a batch, a ring and a shape table of its
     // own: no wave waits for another (there is no barrier below)
     __shared__ __attribute__((aligned(16))) uint32_t rings[kPack][RingCfg<kRows>::kRingWords];
@@ -2146,6 +2146,16 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     int lane = threadIdx.x & 63;
     uint32_t wave = uni(threadIdx.x >> 6);
     uint32_t b = blockIdx.x * kPack + wave;
+    if (big_from) {
+        // Two passes over the batches in one grid (2 n workgroups, kPack 1): those of
+        // big_from bytes and more first, the others behind them.  A wave takes as long
+        // as its batch is large, and the launch ends when the last wave does: large
+        // batches that start last would leave the machine waiting for them alone.
+        uint32_t second = blockIdx.x >= n ? 1u : 0u;
+        b = blockIdx.x - second * n;
+        uint64_t size = batch_off[b + 1] - batch_off[b];
+        if ((size < big_from ? 1u : 0u) != second) return;
+    }
     if (b >= n) return;
     decode_unit<kRows>(false, b, 0, 0, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before, rings[wave],
                        shape_tabs[wave], lane);
