@@ -80,6 +80,7 @@ struct CrcTables {
     // lane_pad_weight[p][l] = lane_weight[l] * inv8[p], a lane's place in the row with p
     // bytes of padding at the row's end divided out.
     alignas(16) uint32_t slice[4][256];
+    uint32_t xpow8_byte[4][256];  // xpow8_byte[k][v] = x^(8 * (v << 8k)): x^(8n) is the product over the bytes of n
     uint32_t lane_pad_weight[kRowBytes][64];
 };
 static_assert(offsetof(CrcTables, slice) % 16 == 0, "the slice tables are loaded sixteen bytes a lane");
@@ -116,6 +117,14 @@ inline void build_crc_tables(CrcTables *t) {
     }
     for (int p = 0; p < kRowBytes; p++)
         for (int l = 0; l < 64; l++) t->lane_pad_weight[p][l] = gf_mulmod(t->lane_weight[l], t->inv8[p]);
+    for (int k = 0; k < 4; k++) {
+        // x^(8 * v * 256^k) = (x^(8 * 256^k))^v, by repeated multiplication
+        uint32_t step = host_xpow(8ull << (8 * k)), r = kOne;
+        for (uint32_t v = 0; v < 256; v++) {
+            t->xpow8_byte[k][v] = r;
+            r = gf_mulmod(r, step);
+        }
+    }
     t->chunk_weight = host_xpow(8ull * kChunkBytes);
     t->chunk_pow[0] = t->chunk_weight;
     for (int k = 1; k < 7; k++) t->chunk_pow[k] = gf_mulmod(t->chunk_pow[k - 1], t->chunk_pow[k - 1]);
@@ -125,8 +134,17 @@ inline void build_crc_tables(CrcTables *t) {
 
 // x^(8n) mod P from the table of x^(8 * 2^k)
 __device__ inline uint32_t gf_xpow8(const CrcTables *t, uint64_t n) {
-    uint32_t r = kOne;
-    for (int k = 0; n; k++, n >>= 1)
+    // a factor a byte of n from the tables (three multiplications below 4 GiB); what
+    // lies above bit 31 bit by bit
+    uint32_t lo = (uint32_t)n;
+    uint32_t r = t->xpow8_byte[0][lo & 0xffu];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        uint32_t v = (lo >> (8 * k)) & 0xffu;
+        if (v) r = gf_mulmod(r, t->xpow8_byte[k][v]);
+    }
+    n >>= 32;
+    for (int k = 32; n; k++, n >>= 1)
         if (n & 1) r = gf_mulmod(r, t->pow8[k]);
     return r;
 }
