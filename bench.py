@@ -162,6 +162,10 @@ def main():
     name = state["dominant"]
     ms, launches = kt[name]
     avg_ms = ms / launches
+    if "chunk_kernel" not in kt_all:
+        # the chunks of large batches were worked on inside the fused kernel's launch
+        # (calls of large batches): that kernel then has all the bytes of the decode
+        stats["chunk_share"] = 0.0
     k_bytes = KERNEL_BYTES.get(name, lambda s: 0)(stats)
     achieved = k_bytes / (avg_ms * 1e-3) / 1e9
     # HBM-side bytes per launch of that kernel, from the counter passes of a committed

@@ -80,6 +80,7 @@ struct CrcTables {
     // lane_pad_weight[p][l] = lane_weight[l] * inv8[p], a lane's place in the row with p
     // bytes of padding at the row's end divided out.
     alignas(16) uint32_t slice[4][256];
+    uint32_t chunk_wpow[64];      // W^k, k = 0 .. 63
     uint32_t xpow8_byte[4][256];  // xpow8_byte[k][v] = x^(8 * (v << 8k)): x^(8n) is the product over the bytes of n
     uint32_t lane_pad_weight[kRowBytes][64];
 };
@@ -126,6 +127,8 @@ inline void build_crc_tables(CrcTables *t) {
         }
     }
     t->chunk_weight = host_xpow(8ull * kChunkBytes);
+    t->chunk_wpow[0] = kOne;
+    for (int k = 1; k < 64; k++) t->chunk_wpow[k] = gf_mulmod(t->chunk_wpow[k - 1], t->chunk_weight);
     t->chunk_pow[0] = t->chunk_weight;
     for (int k = 1; k < 7; k++) t->chunk_pow[k] = gf_mulmod(t->chunk_pow[k - 1], t->chunk_pow[k - 1]);
 }

@@ -488,12 +488,12 @@ __device__ inline uint32_t crc_combine(const uint64_t *batch_off, const int32_t 
     return ~r;
 }
 
-// The same by a whole wave (b and chunks the same in every lane), for batches of
-// many chunks: a multiplication mod P is a chain of 32 dependent steps (0.45 us
-// for a wave alone on its SIMD), and the chain above has one a chunk.  Here the
-// residues are summed as a weighted prefix sum over the lanes,
-//   v_i <- v_(i-d) * W^d + v_i,  d = 1, 2, 4 .. 32,
-// after which lane 63 holds sum_j R_j * W^(63-j): six multiplications for 64 chunks.
+// The same by a whole wave (b and chunks the same in every lane): the residues of
+// the full chunks 64 at a time, one a lane, each multiplied by its weight within
+// the group from the table of W^k (lane 63 is the group's last chunk: W^0) and
+// added up over the lanes; a group weighs W^64 against the next; x^(8 * last_bytes)
+// from the table a byte of the exponent.  Four multiplications for a batch of up
+// to 65 chunks, where the chain above has one a chunk.
 __device__ inline uint32_t crc_combine_wave(const uint64_t *batch_off, const int32_t *batch_length,
                                             uint32_t b, uint32_t chunks, const uint32_t *part, const CrcTables *t,
                                             int lane) {
@@ -502,26 +502,18 @@ __device__ inline uint32_t crc_combine_wave(const uint64_t *batch_off, const int
     uint64_t grid = lo & ~uint64_t(15);
     uint64_t last_bytes = hi - (grid + (uint64_t)(chunks - 1) * kChunkBytes);
     uint32_t m = chunks - 1;  // residues of full chunks, each weighing W against the next
+    uint32_t weight = t->chunk_wpow[63 - lane];
     uint32_t r = 0;
     // 64 at a time from the left; the first group is the short one, padded with zeros on its left
     for (uint32_t done = 0; done < m;) {
         uint32_t size = done == 0 && (m & 63) ? (m & 63) : 64;
         uint32_t pad = 64 - size;
         uint32_t v = (uint32_t)lane >= pad ? part[done + (uint32_t)lane - pad] : 0;
-#pragma unroll 1
-        for (int k = 0; k < 6; k++) {
-            uint32_t x = __shfl_up(v, 1u << k, 64);
-            if (lane < (1 << k)) x = 0;
-            v ^= gf_mulmod(x, t->chunk_pow[k]);  // W^(2^k)
-        }
-        r = (done ? gf_mulmod(r, t->chunk_pow[6]) : 0u) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 63);  // W^64
+        uint32_t g = wave_xor(gf_mulmod(v, weight));
+        r = (done ? gf_mulmod(r, t->chunk_pow[6]) : 0u) ^ g;  // W^64
         done += size;
     }
-    // x^(8 * last_bytes): the product of the table's entries for the bits set, over the lanes
-    uint32_t f = lane < 40 && ((last_bytes >> lane) & 1) ? t->pow8[lane] : kOne;
-#pragma unroll 1
-    for (int d = 1; d < 64; d <<= 1) f = gf_mulmod(f, (uint32_t)__shfl_xor((int)f, d, 64));
-    r = gf_mulmod(r, f) ^ part[chunks - 1];
+    r = gf_mulmod(r, gf_xpow8(t, last_bytes)) ^ part[chunks - 1];
     return ~r;
 }
 
@@ -1897,11 +1889,22 @@ struct ChunkItems {
 
 // One unit of decode_fused_kernel's work: batch b, or with `seg` its chunk `chunk`
 // (CRC work item `mine`).  `seg` is a constant where this is called.
+//
+// `phase` (of a batch, not of a chunk) says what the launch is there for:
+//   kPhaseAll     every batch; the chunks of large batches are through (chunk_kernel ran before).
+//   kPhaseBeside  the chunks are being worked on by other waves of this launch: every
+//                 batch but those decoded chunk by chunk; of a batch whose chunks only
+//                 give its CRC everything but that CRC.
+//   kPhaseAfter   what kPhaseBeside left: the batches decoded chunk by chunk (do the
+//                 chunks join up? else the batch is walked here) and the CRCs from chunks.
+constexpr uint32_t kPhaseAll = 0, kPhaseBeside = 1, kPhaseAfter = 2;
+
 template <int kRows>
 __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk, uint32_t mine, const uint8_t *blob,
                                             const uint64_t *batch_off, uint32_t n, const nisshi_columns &c, const Work &w,
                                             uint64_t rec_cap, uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed,
-                                            const uint64_t *before, uint32_t *ring, uint32_t *shape_tab, int lane) {
+                                            const uint64_t *before, uint32_t *ring, uint32_t *shape_tab, int lane,
+                                            uint32_t phase = kPhaseAll) {
 #ifdef NISSHI_PHASES
     uint64_t tl[6];
     uint64_t wall0 = wall_clock64();
@@ -1909,6 +1912,8 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
 #endif
     uint32_t chunks = uni(w.n_chunks[b]);
     uint32_t flags = uni(w.flags[b]);
+    if (!seg && phase == kPhaseBeside && (flags & kFlagSeg)) return;
+    if (!seg && phase == kPhaseAfter && !(flags & kFlagChunks)) return;
     int status = (int)uni((uint32_t)c.status[b]);
     uint32_t count = uni(c.record_count[b]);
     // The unit's first rows are asked for before anything else is worked out: where
@@ -1928,7 +1933,7 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     // here like any other, but for the CRC.
     bool in_chunks = !seg && (flags & kFlagChunks);
     bool joined_up = false;
-    if (in_chunks) {
+    if (in_chunks && phase != kPhaseBeside) {
         uint32_t first_item = chunk_first(w, b, prefixed != 0, lane);
         uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, chunks, w.partial + first_item, t, lane);
         if (lane == 0) c.crc_computed[b] = v;
@@ -1944,6 +1949,7 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         }
 #endif
     }
+    if (in_chunks && phase == kPhaseAfter && !(flags & kFlagSeg)) return;  // (walked beside its chunks: only the CRC was left)
     bool streamed = chunks != 0 && !joined_up && !(in_chunks && status != NISSHI_OK);  // (nothing to walk, and the CRC is there)
 #ifdef NISSHI_DIAG_NOSTREAM  // diagnostic builds only: what the kernel costs without parts of its work
     streamed = false;
@@ -2133,32 +2139,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
 // One wave per batch: CRC-32C of the batch streamed just ahead of the record
 // walk through an LDS ring, so the batch is read from HBM once.
-template <int kRows, int kWaves, int kPack>
+// kPhased: the launch is one of the two of a call whose chunks are worked on beside
+// its batches (kPhaseBeside, kPhaseAfter; kPack 1); else chunk_groups and phase are
+// not looked at and the kernel is the plain one.
+template <int kRows, int kWaves, int kPack, bool kPhased>
 __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
                                                           const uint64_t *batch_off, uint32_t n,
                                                           nisshi_columns c, Work w, uint64_t rec_cap,
                                                           uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed,
-                                                          const uint64_t *before, uint32_t big_from) {
+                                                          const uint64_t *before, uint32_t big_from,
+                                                          uint32_t chunk_groups, uint32_t phase) {
     // kPack waves a workgroup, each with a batch, a ring and a shape table of its
     // own: no wave waits for another (there is no barrier below)
     __shared__ __attribute__((aligned(16))) uint32_t rings[kPack][RingCfg<kRows>::kRingWords];
     __shared__ __attribute__((aligned(16))) uint32_t shape_tabs[kPack][kShapeWords];
     int lane = threadIdx.x & 63;
     uint32_t wave = uni(threadIdx.x >> 6);
-    uint32_t b = blockIdx.x * kPack + wave;
+    static_assert(!kPhased || kPack == 1, "chunks beside batches: a wave a workgroup");
+    if (kPhased && blockIdx.x < chunk_groups) {
+        // The first chunk_groups workgroups (kPhaseBeside, kPack 1) do chunk_kernel's
+        // work inside this launch: the chunks of large batches are the largest units
+        // of work and start first, the batches fill the machine up behind them.
+        ChunkItems items;
+        items.init(w, n, prefixed != 0, lane);
+        for (uint32_t item = blockIdx.x; item < items.total; item += chunk_groups) {
+            uint32_t cb, chunk;
+            items.locate(w, item, lane, cb, chunk);
+            if (uni(w.flags[cb]) & kFlagSeg)
+                decode_unit<kRows>(true, cb, chunk, item, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before,
+                                   rings[0], shape_tabs[0], lane);
+            else
+                crc_chunk_one(item, cb, chunk, blob, batch_off, c.batch_length, c.crc_computed, w, t, lane);
+        }
+        return;
+    }
+    uint32_t at = blockIdx.x - (kPhased ? chunk_groups : 0u);
+    uint32_t b = at * kPack + wave;
     if (big_from) {
         // Two passes over the batches in one grid (2 n workgroups, kPack 1): those of
         // big_from bytes and more first, the others behind them.  A wave takes as long
         // as its batch is large, and the launch ends when the last wave does: large
         // batches that start last would leave the machine waiting for them alone.
-        uint32_t second = blockIdx.x >= n ? 1u : 0u;
-        b = blockIdx.x - second * n;
+        uint32_t second = at >= n ? 1u : 0u;
+        b = at - second * n;
         uint64_t size = batch_off[b + 1] - batch_off[b];
         if ((size < big_from ? 1u : 0u) != second) return;
     }
     if (b >= n) return;
     decode_unit<kRows>(false, b, 0, 0, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before, rings[wave],
-                       shape_tabs[wave], lane);
+                       shape_tabs[wave], lane, kPhased ? phase : kPhaseAll);
 }
 
 // Batches of a few hundred bytes, a lane each: a workgroup a batch spends more on
