@@ -167,3 +167,67 @@ def test_batches_of_many_records_are_written_in_pieces(codec):
     assert st == C.OK and got == want
     # the input but for the CRC fields, which the test's batches carry as the decoder computed them
     assert got == d_blob.cpu().numpy()[:len(blob)].tobytes()
+
+
+def test_scheduling_switches_give_the_same_columns(codec):
+    """Which launch works on the chunks (beside the batches in the fused kernel's
+    launch, or in a launch of their own before it) and in which order the batches
+    start (those above the mean size first, or as they lie) changes no column: a
+    call with batches that join, one that does not, one of large records and small
+    ones in between, through every setting of the context's switches."""
+    import os
+    rng = np.random.default_rng(11)
+    joining = build_batch(dict(base_offset=0, last_offset_delta=5999), records(6000, rng, headers=lambda i: 1))
+    gaps = build_batch(dict(base_offset=6000, last_offset_delta=11999), records(4000, rng, od=lambda i: 3 * i))
+    large = build_batch(dict(base_offset=20000, last_offset_delta=5),
+                        records(6, rng, value=lambda i: 150_000, key=lambda i: None))
+    small = [build_batch(dict(base_offset=30000 + 10 * i, last_offset_delta=9), records(10, rng, headers=lambda i: i % 3))
+             for i in range(20)]
+    batches = small[:7] + [joining] + small[7:12] + [gaps, large] + small[12:]
+    g, c, totals, *_ = decode(codec, batches)
+    assert totals.n_failed == 0
+    header_level = {f for _, fields in C.HEADER_GROUPS for f in fields}
+    blob = np.frombuffer(b"".join(batches), dtype=np.uint8).copy()
+    off = offsets_of(batches)
+    crc_patch(codec, blob, off)
+    for beside, big_first in ((0, 0), (0, 1), (1, 0)):
+        os.environ["NISSHI_CHUNKS_BESIDE"] = str(beside)
+        os.environ["NISSHI_BIG_FIRST"] = str(big_first)
+        try:
+            other = hip.Codec(0)
+            g2, c2, totals2, *_ = check_against_oracle(other, blob, off)
+            other.close()
+        finally:
+            del os.environ["NISSHI_CHUNKS_BESIDE"], os.environ["NISSHI_BIG_FIRST"]
+        assert (totals2.n_records, totals2.n_headers) == (totals.n_records, totals.n_headers)
+        for name in g:
+            n = totals.n_headers if name in header_level else len(g[name])
+            assert (g[name][:n] == g2[name][:n]).all(), (name, beside, big_first)
+
+
+def test_a_shape_guess_that_does_not_fit(codec):
+    """The walking waves start with the shape of the first record of the first batch
+    of their block of 256 batches in hand.  Here that batch is unlike the others of
+    its block (another shape, no records at all, a first record that does not
+    decode, a compressed batch): the guess is tested against records like any shape
+    and costs nothing but the learning.  600 batches, so three blocks."""
+    rng = np.random.default_rng(12)
+
+    def plain(i):
+        return build_batch(dict(base_offset=100 * i, last_offset_delta=69), records(70, rng, headers=lambda j: 2))
+
+    firsts = [
+        build_batch(dict(base_offset=0, last_offset_delta=9), records(10, rng, value=lambda j: 7, key=lambda j: None)),
+        build_batch(dict(base_offset=25600, last_offset_delta=0), []),
+        None,
+    ]
+    damaged = bytearray(plain(512))
+    damaged[61 + 3] = 0xff  # the first record's timestamp delta runs on into the offset delta: it no longer decodes as its length says
+    damaged[61 + 4] = 0xff
+    firsts[2] = bytes(damaged)
+    batches = []
+    for i in range(600):
+        batches.append(firsts[i // 256] if i % 256 == 0 else plain(i))
+    g, c, totals, *_ = decode(codec, batches)
+    assert totals.n_failed == int((c["status"] != C.OK).sum())
+    assert int(c["status"][1]) == C.OK and int(c["status"][257]) == C.OK
