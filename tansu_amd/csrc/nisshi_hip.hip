@@ -2139,27 +2139,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
 // One wave per batch: CRC-32C of the batch streamed just ahead of the record
 // walk through an LDS ring, so the batch is read from HBM once.
-// kPhased: the launch is one of the two of a call whose chunks are worked on beside
-// its batches (kPhaseBeside, kPhaseAfter; kPack 1); else chunk_groups and phase are
-// not looked at and the kernel is the plain one.
-template <int kRows, int kWaves, int kPack, bool kPhased>
-__global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(const uint8_t *blob,
-                                                          const uint64_t *batch_off, uint32_t n,
-                                                          nisshi_columns c, Work w, uint64_t rec_cap,
-                                                          uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed,
-                                                          const uint64_t *before, uint32_t big_from,
-                                                          uint32_t chunk_groups, uint32_t phase) {
+// kPhase (see decode_unit): kPhaseAll is the plain kernel; kPhaseBeside and
+// kPhaseAfter are the two launches of a call whose chunks are worked on beside its
+// batches (kPack 1): the first has chunk_groups workgroups at the front of its grid
+// that do chunk_kernel's work.
+template <int kRows, int kPack, uint32_t kPhase>
+__device__ __forceinline__ void fused_body(const uint8_t *blob, const uint64_t *batch_off, uint32_t n, const nisshi_columns &c,
+                                           const Work &w, uint64_t rec_cap, uint64_t hdr_cap, const CrcTables *t,
+                                           uint32_t prefixed, const uint64_t *before, uint32_t big_from,
+                                           uint32_t chunk_groups) {
     // kPack waves a workgroup, each with a batch, a ring and a shape table of its
     // own: no wave waits for another (there is no barrier below)
     __shared__ __attribute__((aligned(16))) uint32_t rings[kPack][RingCfg<kRows>::kRingWords];
     __shared__ __attribute__((aligned(16))) uint32_t shape_tabs[kPack][kShapeWords];
     int lane = threadIdx.x & 63;
     uint32_t wave = uni(threadIdx.x >> 6);
-    static_assert(!kPhased || kPack == 1, "chunks beside batches: a wave a workgroup");
-    if (kPhased && blockIdx.x < chunk_groups) {
-        // The first chunk_groups workgroups (kPhaseBeside, kPack 1) do chunk_kernel's
-        // work inside this launch: the chunks of large batches are the largest units
-        // of work and start first, the batches fill the machine up behind them.
+    static_assert(kPhase == kPhaseAll || kPack == 1, "chunks beside batches: a wave a workgroup");
+    if (kPhase == kPhaseBeside && blockIdx.x < chunk_groups) {
+        // The chunks of large batches are the largest units of work and start first,
+        // the batches fill the machine up behind them.
         ChunkItems items;
         items.init(w, n, prefixed != 0, lane);
         for (uint32_t item = blockIdx.x; item < items.total; item += chunk_groups) {
@@ -2173,7 +2171,7 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
         }
         return;
     }
-    uint32_t at = blockIdx.x - (kPhased ? chunk_groups : 0u);
+    uint32_t at = blockIdx.x - (kPhase == kPhaseBeside ? chunk_groups : 0u);
     uint32_t b = at * kPack + wave;
     if (big_from) {
         // Two passes over the batches in one grid (2 n workgroups, kPack 1): those of
@@ -2187,7 +2185,24 @@ __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWav
     }
     if (b >= n) return;
     decode_unit<kRows>(false, b, 0, 0, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before, rings[wave],
-                       shape_tabs[wave], lane, kPhased ? phase : kPhaseAll);
+                       shape_tabs[wave], lane, kPhase);
+}
+
+template <int kRows, int kWaves, int kPack, bool kBeside>
+__global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(
+    const uint8_t *blob, const uint64_t *batch_off, uint32_t n, nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap,
+    const CrcTables *t, uint32_t prefixed, const uint64_t *before, uint32_t big_from, uint32_t chunk_groups) {
+    fused_body<kRows, kPack, kBeside ? kPhaseBeside : kPhaseAll>(blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before,
+                                                                  big_from, chunk_groups);
+}
+
+// What a launch with chunks beside batches left: a wave a batch, of which those
+// whose chunks were work items have something to do (kPhaseAfter).
+template <int kRows, int kWaves>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_after_chunks_kernel(
+    const uint8_t *blob, const uint64_t *batch_off, uint32_t n, nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap,
+    const CrcTables *t, uint32_t prefixed, const uint64_t *before) {
+    fused_body<kRows, 1, kPhaseAfter>(blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before, 0u, 0u);
 }
 
 // Batches of a few hundred bytes, a lane each: a workgroup a batch spends more on
