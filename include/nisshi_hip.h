@@ -129,14 +129,19 @@ typedef struct nisshi_totals {
 typedef struct nisshi_hip_ctx nisshi_hip_ctx;
 
 /* Create a context on a HIP device; fails with NISSHI_DEVICE_ERROR when no
- * usable gfx950 device is present.  There is no CPU fallback.  Three settings are
+ * usable gfx950 device is present.  There is no CPU fallback.  Five settings are
  * read from the environment here: NISSHI_SLICE_BYTES (the slice of the
  * host-buffer decode, see nisshi_hip_decode), NISSHI_WIDE_RING_FROM (the mean
  * batch size in bytes from which the decode kernel streams a batch through
  * twelve 1 KiB rows of LDS at three waves a SIMD instead of eight at four;
  * default 65536) and NISSHI_SEG_FEW_BATCHES (calls of fewer batches than this
  * decode their batches of 128 KiB and more a wave a 64 KiB chunk, calls of more
- * only those of 512 KiB and more; default 6144).  None changes any result. */
+ * only those of 512 KiB and more; default 6144), NISSHI_CHUNKS_BESIDE (0: the
+ * chunks of large batches get a launch of their own ahead of the batches' in
+ * every call; default 1: calls of few large batches work on them inside the
+ * batches' launch) and NISSHI_BIG_FIRST (0: the batches start in the order they
+ * lie in; default 1: in calls of large batches those above the mean size start
+ * first).  None changes any result. */
 int nisshi_hip_ctx_create(int device, nisshi_hip_ctx **ctx);
 void nisshi_hip_ctx_destroy(nisshi_hip_ctx *ctx);
 const char *nisshi_hip_status_str(int status);
