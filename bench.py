@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+EVENTS_EVERY = 4       # of the timed steps one in this many carries the two events around the dominant kernel
 
 # Which input bytes and which columns each decode kernel is responsible for, as
 # a fraction of the algorithmic bytes of a decode:
@@ -131,15 +132,16 @@ def main():
     # The warm-up steps run with an event after every kernel: they give every kernel's
     # share of a step and say which kernel takes most of it.  The timed steps run
     # with events around that kernel only (an event between two kernels keeps them a
-    # few microseconds apart, which a caller's decode does not pay): its duration
-    # over the timed region is what the roofline is computed from.
+    # few microseconds apart, which a caller's decode does not pay), and only one
+    # step in EVENTS_EVERY: that kernel's duration over those launches of the timed
+    # region is what the roofline is computed from.
     state = {"all": {}, "dominant": "decode_fused_kernel"}
 
     def on_start():
         state["all"] = codec.kernel_times()
         if state["all"]:
             state["dominant"] = max(state["all"].items(), key=lambda kv: kv[1][0])[0]
-        codec.profile(True, only=state["dominant"])
+        codec.profile(True, only=state["dominant"], every=EVENTS_EVERY)
 
     codec.profile(True)
     elapsed = shard.run_timed(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev),
@@ -221,6 +223,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_source,
             "kernel_ms": avg_ms,
+            "kernel_launches_timed": launches,
             "kernel_algorithmic_bytes": k_bytes,
         },
         # (from the warm-up steps, an event after every kernel)

@@ -505,7 +505,9 @@ int nisshi_hip_crc32c_dev(nisshi_hip_ctx *ctx, const uint8_t *d_data, uint64_t l
  * count of one kernel since the last _enable.  _name returns NULL past the last
  * kernel id.  on = 1: every kernel; on = 2 + k: only kernel k of a decode call (an
  * event before it and one after it: the other kernels run as they do unobserved,
- * an event between two kernels keeps them a few microseconds apart); 0: off.  Has
+ * an event between two kernels keeps them a few microseconds apart), and with
+ * (p - 1) << 8 added only in one decode call of p, the others entirely
+ * unobserved; 0: off.  Has
  * no counterpart in the reference (it instruments with the tracing crate, e.g.
  * src/record.rs:215, 234, 255). */
 int nisshi_hip_profile_enable(nisshi_hip_ctx *ctx, int on);

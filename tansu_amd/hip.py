@@ -315,8 +315,9 @@ class Codec:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- per-kernel timing ----------------------------------------------------
-    def profile(self, on: bool, only: Optional[str] = None):
-        """Per-kernel event marks on or off; `only`: the name of the one decode kernel to time."""
+    def profile(self, on: bool, only: Optional[str] = None, every: int = 1):
+        """Per-kernel event marks on or off; `only`: the name of the one decode kernel to
+        time, in one decode call of `every` (the other calls carry no events at all)."""
         mode = int(bool(on))
         if on and only is not None:
             k = 0
@@ -327,7 +328,7 @@ class Codec:
                 if name.decode() == only:
                     break
                 k += 1
-            mode = 2 + k
+            mode = 2 + k + ((max(1, min(every, 256)) - 1) << 8)
         self._check(self.lib.nisshi_hip_profile_enable(self.ctx, mode))
 
     def kernel_times(self) -> dict:
