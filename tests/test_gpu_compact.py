@@ -110,6 +110,13 @@ def test_large_partition(codec):
     check_host(codec, batches)
 
 
+def test_hot_keys_and_short_batches(codec):
+    """Three keys over tens of thousands of records (nearly every record meets an entry whose highest slot
+    is already above its own), batches so short that a wave's slots lie in several of them."""
+    removed = check_host(codec, make_partition(3000, 37, 3, seed=5, keyless=0.05))
+    assert removed.sum() > 50000
+
+
 def test_failed_and_empty(codec):
     batches = make_partition(4, 20, 5, seed=3)
     got, removed, action, status, _ = codec.compact(b"", np.zeros(1, dtype=np.uint64))

@@ -1,10 +1,13 @@
-"""Per-kernel times of the fetch seam and of log compaction at the C2 size."""
+"""Per-kernel times of the fetch seam and of log compaction at the C2 size.
+KEYS=k in the environment gives the records k distinct keys (record r gets key r mod k) instead of one each."""
 import sys, os, json, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 from tansu_amd import hip, synth
 
+if os.environ.get("LIB"):
+    hip.LIB_PATH = os.path.abspath(os.environ["LIB"])
 codec = hip.Codec(0)
 dev = codec.device
 shape, counts, seed = synth.config(os.environ.get("CFG", "c2"), float(os.environ.get("SCALE", "1.0")))
@@ -42,6 +45,15 @@ keep["producer_id"] = (torch.arange(nr, device=dev) // 1000).long()
 c = hip.CFetchRows()
 for name, _, _ in hip.FETCH_ARRAYS:
     setattr(c, name, keep[name].data_ptr())
+n_keys = int(os.environ.get("KEYS", "0"))
+if n_keys:
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    table = torch.randint(0, 256, (n_keys, 16), dtype=torch.uint8, device=dev, generator=gen)
+    at = keep["key_off"].long()
+    for j in range(16):
+        d_blob[at + j] = table[torch.arange(nr, device=dev) % n_keys, j]
+    del table, at
 out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=dev)
 out_off = torch.zeros(n_b + 2, dtype=torch.int64, device=dev)
 codec.profile(True)
@@ -52,7 +64,7 @@ for i in range(reps):
     ccols, removed, action, tot = codec.compact_dev(d_blob, cols, n_b, nr)
 torch.cuda.synchronize()
 res = {k: round(ms / n, 4) for k, (ms, n) in codec.kernel_times().items()}
-res.update(records=nr, headers=nh, batches=n_b, blob=len(blob), fetch_batches=nb, kept=int(tot.n_records))
+res.update(records=nr, headers=nh, batches=n_b, blob=len(blob), fetch_batches=nb, kept=int(tot.n_records), keys=n_keys)
 # the fetched batches carry the records of the decoded ones
 back = hip.DeviceColumns(nb, nr, max(nh, 1) + 4096, dev)
 t2 = codec.decode_dev(out, int(out_off[nb]), out_off, nb, back)
