@@ -117,6 +117,50 @@ def test_hot_keys_and_short_batches(codec):
     assert removed.sum() > 50000
 
 
+def test_full_size_last_of_each_key(codec):
+    """At the benchmark's size (8192 batches of 1000 records) the oracle is too slow for a test; the
+    domain's own property instead: with record r carrying key r mod K, the records that stay are exactly
+    the last K of the log, every batch before them is emptied, the one they begin in is rewritten, and
+    compacting what is left removes nothing."""
+    import torch
+    from tansu_amd import synth
+    shape, counts, seed = synth.config("c2", 1.0)
+    blob, off, nr, nh = synth.make_batches(shape, counts, seed)
+    n_b = len(counts)
+    cols, totals, d_blob, d_off = gpu_decode(codec, blob, off, rec_cap=nr, hdr_cap=max(nh, 1))
+    assert (totals.n_records, totals.n_failed) == (nr, 0)
+    dev = codec.device
+    K = 100_003
+    count = torch.as_tensor(np.asarray(counts), device=dev).long()
+    slot = torch.arange(nr, device=dev)
+    key_at = torch.repeat_interleave(cols.t["data_off"][:n_b].long(), count) + cols.field("key_off")[:nr].long()
+    assert bool((cols.field("key_len")[:nr] == 16).all())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    keys = torch.randint(0, 256, (K, 16), dtype=torch.uint8, device=dev, generator=gen)
+    for j in range(4):                                     # distinct whatever the draw: the index in four bytes
+        keys[:, j] = ((torch.arange(K, device=dev) >> (8 * j)) & 0xFF).to(torch.uint8)
+    for j in range(16):
+        d_blob[key_at + j] = keys[slot % K, j]
+    out, removed, action, t = codec.compact_dev(d_blob, cols, n_b, nr)
+    assert t.n_records == K
+    base = cols.t["rec_base"][:n_b].long()
+    want = torch.clamp(base + count - (nr - K), min=0).minimum(count)
+    assert bool((out.t["record_count"][:n_b].long() == want).all())
+    assert bool((removed[:n_b].long() == count - want).all())
+    want_action = torch.where(want == count, 0, torch.where(want > 0, 1, 2))
+    assert bool((action[:n_b].long() == want_action).all())
+    # the kept records are the last K, in order
+    f, g = cols.field, out.field
+    for name in ("offset_delta", "key_off", "key_len", "val_off", "val_len", "timestamp_delta", "rhdr_base"):
+        assert bool((g(name)[:K] == f(name)[nr - K:nr]).all()), name
+    # what is left, taken as a log again (the operator marks only the rewritten batches OK)
+    left = out.t["record_count"][:n_b] > 0
+    out.t["status"][:n_b] = torch.where(left, torch.zeros_like(out.t["status"][:n_b]), out.t["status"][:n_b])
+    again, removed2, action2, t2 = codec.compact_dev(d_blob, out, n_b, K)
+    assert t2.n_records == K and int(removed2.sum()) == 0 and int(action2.sum()) == 0
+
+
 def test_failed_and_empty(codec):
     batches = make_partition(4, 20, 5, seed=3)
     got, removed, action, status, _ = codec.compact(b"", np.zeros(1, dtype=np.uint64))
