@@ -136,6 +136,78 @@ def test_produce_then_fetch_round_trip(codec):
         assert a.timestamp_delta - first_ts == b.timestamp_delta
 
 
+def test_full_size_produce_then_fetch(codec):
+    """At the benchmark's size (8192 batches of 1000 small records, two headers each) the oracle is too
+    slow for a test; the round trip instead: the rows the produce seam writes for the decoded batches,
+    read back by the fetch seam and deflated, are the input again byte for byte but for the 61-byte batch
+    headers (the records' lengths and deltas are canonical in this workload, each batch's rows have a
+    producer id of their own, the deltas count from the batch's first row as they did), and the rebuilt
+    headers carry the offsets the rows were given."""
+    import torch
+    from tansu_amd import synth
+    from test_gpu_parity import gpu_decode
+    dev = codec.device
+    shape, counts, seed = synth.config("c2", 1.0)
+    blob, off, nr, nh = synth.make_batches(shape, counts, seed)
+    n_b = len(counts)
+    cols, totals, d_blob, d_off = gpu_decode(codec, blob, off, rec_cap=nr, hdr_cap=max(nh, 1))
+    assert (totals.n_records, totals.n_headers, totals.n_failed) == (nr, nh, 0)
+    per = int(counts[0])
+    high = torch.arange(n_b, device=dev, dtype=torch.int64) * per + 7_000_000
+    rows = codec.produce_rows_dev(cols, n_b, nr, high, True)
+    assert bool((rows.t["offset"][:nr] == torch.arange(nr, device=dev) + 7_000_000).all())
+    # the rows a storage engine would hand back: spans as offsets into the blob, headers in record order
+    rkey = cols.t["rkey"][:nr].view(torch.int32).reshape(nr, 4)
+    rval = cols.t["rval"][:nr].view(torch.int32).reshape(nr, 4)
+    batch = rows.t["batch"][:nr].long()
+    base = cols.t["data_off"][:n_b][batch]
+    hc = rval[:, 3].long()
+    hb = torch.zeros(nr + 1, dtype=torch.int64, device=dev)
+    hb[1:] = torch.cumsum(hc, 0)
+    assert int(hb[-1]) == nh
+    within = torch.arange(nh, device=dev) - torch.repeat_interleave(hb[:-1], hc)
+    src = torch.repeat_interleave(rval[:, 2].long() & 0xffffffff, hc) + within
+    hdr = cols.t["hdr"].view(torch.int32).reshape(-1, 4)[src].clone()
+    hbase = torch.repeat_interleave(base, hc).int()
+    hdr[:, 0] += hbase
+    hdr[:, 2] += hbase
+    del within, src, hbase
+    keep = dict(offset=rows.t["offset"][:nr].clone(), attributes=torch.zeros(nr, dtype=torch.int16, device=dev),
+                timestamp=rows.t["timestamp"][:nr].clone(), producer_id=batch.clone(),
+                producer_epoch=torch.full((nr,), -1, dtype=torch.int16, device=dev),
+                completed=torch.ones(nr, dtype=torch.uint8, device=dev),
+                key_off=(rkey[:, 2].long() + base).int(), key_len=rkey[:, 3].contiguous(),
+                val_off=(rval[:, 0].long() + base).int(), val_len=rval[:, 1].contiguous(),
+                hdr_base=hb.int(), hdr=hdr.contiguous())
+    c = hip.CFetchRows()
+    for name, _, _ in hip.FETCH_ARRAYS:
+        setattr(c, name, keep[name].data_ptr())
+    fcols, nb = codec.fetch_batches_dev(c, keep["hdr"], nr, NOW, n_b + 1)
+    assert nb == n_b
+    out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=dev)
+    out_off = torch.zeros(n_b + 1, dtype=torch.int64, device=dev)
+    te = codec.encode_dev(fcols, nb, d_blob, fcols.t["data_off"], out, len(blob), out_off)
+    assert te.out_bytes == len(blob)
+    assert bool((out_off.cpu() == torch.from_numpy(off.astype(np.int64))).all())
+    body = torch.ones(len(blob), dtype=torch.bool, device=dev)
+    starts = d_off[:n_b].long()
+    for k in range(61):
+        body[starts + k] = False
+    assert bool((out[:len(blob)][body] == d_blob[:len(blob)][body]).all())
+    del body
+    back = hip.DeviceColumns(n_b, nr, max(nh, 1), dev)
+    t2 = codec.decode_dev(out, len(blob), out_off, n_b, back)
+    assert (t2.n_records, t2.n_headers, t2.n_failed) == (nr, nh, 0)
+    bt = back.t
+    assert bool((bt["crc"][:n_b] == bt["crc_computed"][:n_b]).all())
+    assert bool((bt["base_offset"][:n_b] == high).all())
+    assert bool((bt["record_count"][:n_b] == per).all()) and bool((bt["last_offset_delta"][:n_b] == per - 1).all())
+    assert bool((bt["producer_id"][:n_b] == torch.arange(n_b, device=dev)).all())
+    first = rows.t["timestamp"][:nr].view(n_b, per)
+    assert bool((bt["base_timestamp"][:n_b] == first[:, 0]).all())
+    assert bool((bt["max_timestamp"][:n_b] == NOW).all())    # the builder's default, as the reference leaves it
+
+
 def builder_fields_of(batch: bytes):
     """inflated::Builder::build's batch_length and crc for a deflated batch, by the
     CPU restatement: inflate it, into_builder(), build()."""
