@@ -1,5 +1,6 @@
-"""The mixed workload's kinds of partitions one at a time and together: decode kernel times.
-python tools/c4_parts.py <lib.so>"""
+"""The mixed workload's kinds of partitions one at a time and together: decode kernel times,
+and with --enc those of the re-encode.
+python tools/c4_parts.py <lib.so> [--enc]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -17,6 +18,10 @@ def blob_of(parts):
 sets = {"kind%d" % k: [8 * j for j in range(128) if (8 * j) % 5 == k] for k in range(5)}
 sets["all"] = [8 * j for j in range(128)]
 sets["kinds12"] = [8 * j for j in range(128) if (8 * j) % 5 in (1, 2)]
+for k in (0, 3, 4):
+    sets["without%d" % k] = [8 * j for j in range(128) if (8 * j) % 5 != k]
+if os.environ.get("SETS"):
+    sets = {k: v for k, v in sets.items() if k in os.environ["SETS"].split(",")}
 for name, only in sets.items():
     parts = synth.mixed_partitions(1024, 64, only=only)
     blob, off, nr, nh = blob_of(parts)
@@ -38,5 +43,16 @@ for name, only in sets.items():
     torch.cuda.synchronize()
     res = {k.replace("_kernel", ""): round(ms / n, 4) for k, (ms, n) in codec.kernel_times().items()}
     codec.profile(False)
-    print(json.dumps({"set": name, "batches": nb, "MB": round(len(blob) / 1e6, 1), "step_ms": round(step, 4), "kernels": res}), flush=True)
+    enc = None
+    if "--enc" in sys.argv:
+        out = torch.zeros(len(blob) + 64, dtype=torch.uint8, device=codec.device)
+        out_off = torch.zeros(nb + 1, dtype=torch.int64, device=codec.device)
+        codec.profile(True)
+        for i in range(10):
+            codec.encode_dev(cols, nb, d_blob, cols.t["data_off"], out, len(blob), out_off, sync=False)
+        torch.cuda.synchronize()
+        enc = {k.replace("_kernel", ""): round(ms / n, 4) for k, (ms, n) in codec.kernel_times().items()}
+        codec.profile(False)
+        del out, out_off
+    print(json.dumps({"set": name, "enc": enc, "batches": nb, "MB": round(len(blob) / 1e6, 1), "step_ms": round(step, 4), "kernels": res}), flush=True)
     del d_blob, d_off, cols
