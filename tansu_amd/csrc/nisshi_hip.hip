@@ -594,11 +594,44 @@ __device__ __forceinline__ uint64_t blocks_before(const Work &w, uint32_t blk, b
 
 // The first record slot and the first expected header slot of batch b.  `before`:
 // the totals of the slice decoded before this one (the slots go on from there), or NULL.
+// In two steps, so that a caller can ask for these values together with others and
+// wait for all of them once: the loads, then the sums.
+struct BasesLoad {
+    uint64_t blocks;  // this lane's share of the blocks before (the running sum itself when prefixed)
+    uint32_t rec_local, hdr_local, rec_before, hdr_before;
+};
+
+__device__ __forceinline__ BasesLoad batch_bases_load(const Work &w, uint32_t b, bool prefixed, const uint64_t *before,
+                                                      int lane) {
+    BasesLoad q;
+    uint32_t blk = b / kSumBlock;
+    q.blocks = 0;
+    if (prefixed) {
+        q.blocks = w.blk_sum[blk];
+    } else {
+        for (uint32_t j = (uint32_t)lane; j < blk; j += 64) q.blocks += w.blk_sum[j];
+    }
+    q.rec_local = w.rec_local[b];
+    q.hdr_local = w.hdr_local[b];
+    q.rec_before = before ? (uint32_t)before[0] : 0u;
+    q.hdr_before = before ? (uint32_t)before[1] : 0u;
+    return q;
+}
+
+__device__ __forceinline__ void batch_bases_sum(const BasesLoad &q, bool prefixed, uint32_t &rec_base, uint32_t &hdr_base) {
+    uint64_t sum = q.blocks;
+    if (!prefixed) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    }
+    rec_base = uni((uint32_t)sum + q.rec_local + q.rec_before);
+    hdr_base = uni((uint32_t)(sum >> 32) + q.hdr_local + q.hdr_before);
+}
+
 __device__ __forceinline__ void batch_bases(const Work &w, uint32_t b, bool prefixed, const uint64_t *before, int lane,
                                             uint32_t &rec_base, uint32_t &hdr_base) {
-    uint64_t sum = blocks_before(w, b / kSumBlock, prefixed, lane);
-    rec_base = uni((uint32_t)sum + w.rec_local[b] + (before ? (uint32_t)before[0] : 0u));
-    hdr_base = uni((uint32_t)(sum >> 32) + w.hdr_local[b] + (before ? (uint32_t)before[1] : 0u));
+    BasesLoad q = batch_bases_load(w, b, prefixed, before, lane);
+    batch_bases_sum(q, prefixed, rec_base, hdr_base);
 }
 
 // The first header slot of a batch whose headers did not fit its expected slots:
@@ -1910,8 +1943,23 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     uint64_t wall0 = wall_clock64();
     tl[0] = __builtin_readcyclecounter();
 #endif
-    uint32_t chunks = uni(w.n_chunks[b]);
-    uint32_t flags = uni(w.flags[b]);
+    // What the unit needs to know of its batch lies at addresses that b alone gives:
+    // all of it is asked for in one go and waited for once, so that the rows can be
+    // asked for one trip to the L2 later and nothing else is waited for before they come.
+    // (The status and the record count are loaded further down, where they are used:
+    // placed here with the others they cost the chained walk 4 %.)
+    uint32_t chunks_v = w.n_chunks[b], flags_v = w.flags[b];
+    asm volatile("" ::: "memory");
+    uint64_t off_v = batch_off[b];
+    uint32_t length_v = (uint32_t)c.batch_length[b], expect_v = w.hdr_pred[b];
+    BasesLoad bases_v = batch_bases_load(w, b, prefixed != 0, before, lane);
+    u32x4 guess = u32x4{0, 0, 0, 0};  // the guess at the shape of the block's records (guess_shape)
+    if (w.shape_guess != nullptr && (uint32_t)lane < kShapeWords / 4) {
+        typedef __attribute__((address_space(1))) const u32x4 gbl_u128;
+        guess = ((gbl_u128 *)(uintptr_t)w.shape_guess)[(uint64_t)(b / kSumBlock) * (kShapeWords / 4) + (uint32_t)lane];
+    }
+    uint32_t chunks = uni(chunks_v);
+    uint32_t flags = uni(flags_v);
     if (!seg && phase == kPhaseBeside && (flags & kFlagSeg)) return;
     if (!seg && phase == kPhaseAfter && !(flags & kFlagChunks)) return;
     int status = (int)uni((uint32_t)c.status[b]);
@@ -1957,8 +2005,8 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     uint32_t row0 = chunk * kChunkRows, fold_to = seg ? row0 + kChunkRows : 0xffffffffu;
     uint32_t bias = 0, x = 0;  // x: the chunk's first byte as a position in the record data
     if (streamed) {
-        uint64_t lo = batch_off[b] + 21;
-        stream.init(blob, lo, lo + (uint64_t)uni(c.batch_length[b]) - 9, (lds_u32 *)ring, lane);
+        uint64_t lo = (((uint64_t)uni((uint32_t)(off_v >> 32)) << 32) | uni((uint32_t)off_v)) + 21;
+        stream.init(blob, lo, lo + (uint64_t)uni(length_v) - 9, (lds_u32 *)ring, lane);
         bias = 40 + stream.lo;
         if (seg) {
             stream.segment(row0, fold_to);
@@ -1972,22 +2020,15 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         n_first = n_first < (uint32_t)kAhead ? n_first : (uint32_t)kAhead;
         stream.load(first_rows, n_first);
     }
-    // the guess at the shape of the block's records (guess_shape), on its way while the bases are worked out
-    u32x4 guess = u32x4{0, 0, 0, 0};
-    bool guessed = streamed && w.shape_guess != nullptr;
-    if (guessed && (uint32_t)lane < kShapeWords / 4) {
-        typedef __attribute__((address_space(1))) const u32x4 gbl_u128;
-        guess = ((gbl_u128 *)(uintptr_t)w.shape_guess)[(uint64_t)(b / kSumBlock) * (kShapeWords / 4) + (uint32_t)lane];
-    }
     // where the batch's records and headers go
+    bool guessed = streamed && w.shape_guess != nullptr;
     uint32_t rec_base, hdr_base;
-    batch_bases(w, b, prefixed != 0, before, lane, rec_base, hdr_base);
-    // (the guess was asked for before the sums were: it is here by now)
+    batch_bases_sum(bases_v, prefixed != 0, rec_base, hdr_base);
     if (guessed && (uint32_t)lane < kShapeWords / 4) ((lds_u128 *)shape_tab)[lane] = guess;
 #ifdef NISSHI_PHASES
     tl[1] = __builtin_readcyclecounter();
 #endif
-    uint32_t expect = uni(w.hdr_pred[b]);
+    uint32_t expect = uni(expect_v);
     if (!seg) {
         if (lane == 0) {
             c.rec_base[b] = rec_base;
@@ -2184,8 +2225,18 @@ __device__ __forceinline__ void fused_body(const uint8_t *blob, const uint64_t *
         if ((size < big_from ? 1u : 0u) != second) return;
     }
     if (b >= n) return;
+#ifdef NISSHI_DIAG_WAVE_TIMES
+    uint64_t diag_t0 = wall_clock64();
+#endif
     decode_unit<kRows>(false, b, 0, 0, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before, rings[wave],
                        shape_tabs[wave], lane, kPhase);
+#ifdef NISSHI_DIAG_WAVE_TIMES
+    // (diagnostic build: when this wave began, on the 100 MHz clock, and how long it took, over two header columns)
+    if (lane == 0) {
+        c.base_sequence[b] = (int32_t)diag_t0;
+        c.partition_leader_epoch[b] = (int32_t)(wall_clock64() - diag_t0);
+    }
+#endif
 }
 
 template <int kRows, int kWaves, int kPack, bool kBeside>
