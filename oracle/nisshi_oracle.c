@@ -1179,3 +1179,140 @@ int no_compact_partition(const uint8_t *const *batches, const size_t *lens, size
     free(counts);
     return st;
 }
+
+/* ------------------------------------------------------------------ Snappy */
+
+/* bytes::read_varu64 of the snap crate: LEB128, up to ten bytes; a shift of 64 and more fails,
+ * bits shifted out below that are lost; no terminating byte fails.  Header::read then refuses a
+ * length above u32::MAX (Error::TooBig). */
+int no_snappy_raw_len(const uint8_t *in, size_t n, size_t *header_len, uint64_t *len) {
+    uint64_t v = 0;
+    unsigned shift = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t b = in[i];
+        if (shift >= 64) return NO_INFLATE;
+        if (b < 0x80) {
+            v |= (uint64_t)b << shift;
+            if (v > 0xffffffffull) return NO_INFLATE;
+            *header_len = i + 1;
+            *len = v;
+            return NO_OK;
+        }
+        v |= (uint64_t)(b & 0x7f) << shift;
+        shift += 7;
+    }
+    return NO_INFLATE; /* (Error::Header: no terminator; an empty input is Error::Empty) */
+}
+
+/* snap::raw::Decoder::decompress into a buffer of the announced length */
+int no_snappy_raw(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    size_t s = 0, d = 0;
+    uint64_t want = 0;
+    *out_len = 0;
+    if (n == 0) return NO_INFLATE;
+    if (no_snappy_raw_len(in, n, &s, &want)) return NO_INFLATE;
+    if (want > cap) return NO_CAPACITY;
+    while (s < n) {
+        uint8_t tag = in[s++];
+        if ((tag & 3) == 0) {
+            uint64_t len = (uint64_t)(tag >> 2) + 1;
+            if (len >= 61) {
+                size_t extra = (size_t)len - 60;
+                if (s + 4 > n) return NO_INFLATE; /* (a literal of 61 bytes and more has them behind it) */
+                uint32_t word = (uint32_t)in[s] | (uint32_t)in[s + 1] << 8 | (uint32_t)in[s + 2] << 16 | (uint32_t)in[s + 3] << 24;
+                if (extra < 4) word &= (1u << (8 * extra)) - 1;
+                len = (uint64_t)word + 1;
+                s += extra;
+            }
+            if ((uint64_t)(n - s) < len || want - d < len) return NO_INFLATE;
+            memcpy(out + d, in + s, (size_t)len);
+            s += (size_t)len;
+            d += (size_t)len;
+        } else {
+            size_t extra = (tag & 3) == 1 ? 1 : (tag & 3) == 2 ? 2 : 4;
+            if (n - s < extra) return NO_INFLATE; /* Error::CopyRead */
+            uint64_t offset, len;
+            if ((tag & 3) == 1) {
+                len = 4 + ((tag >> 2) & 7);
+                offset = ((uint64_t)(tag >> 5) << 8) | in[s];
+            } else if ((tag & 3) == 2) {
+                len = 1 + (tag >> 2);
+                offset = (uint64_t)in[s] | (uint64_t)in[s + 1] << 8;
+            } else {
+                len = 1 + (tag >> 2);
+                offset = (uint64_t)in[s] | (uint64_t)in[s + 1] << 8 | (uint64_t)in[s + 2] << 16 | (uint64_t)in[s + 3] << 24;
+            }
+            s += extra;
+            if (offset == 0 || offset > d) return NO_INFLATE; /* Error::Offset */
+            if (want - d < len) return NO_INFLATE;             /* Error::CopyWrite */
+            for (uint64_t i = 0; i < len; i++, d++) out[d] = out[d - (size_t)offset];
+        }
+    }
+    if (d != want) return NO_INFLATE; /* Error::HeaderMismatch */
+    *out_len = d;
+    return NO_OK;
+}
+
+/* lib.rs:1717-1751 */
+int no_snappy_inflate(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    static const uint8_t magic[8] = {0x82, 'S', 'N', 'A', 'P', 'P', 'Y', 0};
+    *out_len = 0;
+    if (n >= 8 && memcmp(in, magic, 8) == 0) {
+        if (n < 20) return NO_INFLATE; /* (split_at past the end: the reference panics) */
+        in += 20;
+        n -= 20;
+    }
+    return no_snappy_raw(in, n, out, cap, out_len);
+}
+
+int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches, uint8_t *out,
+                     size_t out_cap, uint64_t *out_off, int32_t *status) {
+    size_t at = 0;
+    for (size_t b = 0; b < n_batches; b++) {
+        const uint8_t *p = blob + batch_off[b];
+        size_t len = (size_t)(batch_off[b + 1] - batch_off[b]);
+        out_off[b] = at;
+        status[b] = NO_NONE_DONE;
+        no_deflated_batch h;
+        int st = no_deflated_parse(p, len, &h);
+        int codec = 0;
+        if (st == NO_OK && no_compression(h.attributes, &codec) == NO_OK && codec == 2) {
+            size_t hl = 0, got = 0;
+            uint64_t want = 0;
+            const uint8_t *data = h.record_data;
+            size_t n = h.record_data_len;
+            st = NO_INFLATE;
+            /* the announced length sizes the output before anything is decoded */
+            {
+                static const uint8_t magic[8] = {0x82, 'S', 'N', 'A', 'P', 'P', 'Y', 0};
+                const uint8_t *raw = data;
+                size_t rn = n;
+                int ok = 1;
+                if (n >= 8 && memcmp(data, magic, 8) == 0) {
+                    if (n < 20) ok = 0;
+                    else raw += 20, rn -= 20;
+                }
+                if (ok && rn && no_snappy_raw_len(raw, rn, &hl, &want) == NO_OK && 49 + want <= 0x7fffffffull) {
+                    if (at + 61 + want > out_cap) return NO_CAPACITY;
+                    st = no_snappy_inflate(data, n, out + at + 61, (size_t)want, &got);
+                }
+            }
+            if (st == NO_OK) {
+                memcpy(out + at, p, 61);
+                uint32_t bl = 49 + (uint32_t)got;
+                out[at + 8] = (uint8_t)(bl >> 24), out[at + 9] = (uint8_t)(bl >> 16);
+                out[at + 10] = (uint8_t)(bl >> 8), out[at + 11] = (uint8_t)bl;
+                out[at + 22] &= (uint8_t)~7u; /* attributes: big-endian i16 at 21 */
+                at += 61 + got;
+                status[b] = NO_OK;
+                continue;
+            }
+            status[b] = NO_INFLATE;
+        }
+        if (at + len > out_cap) return NO_CAPACITY;
+        memcpy(out + at, p, len);
+        at += len;
+    }
+    out_off[n_batches] = at;
+    return NO_OK;
+}

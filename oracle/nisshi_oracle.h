@@ -40,7 +40,8 @@ enum {
     NO_UNKNOWN_COMPRESSION = 4,
     NO_PANIC = 5,
     NO_COMPRESSED = 6,
-    NO_CAPACITY = 7
+    NO_CAPACITY = 7,
+    NO_INFLATE = 11 /* the compressed record data does not inflate (Error::Snap / Error::Io from the inflator) */
 };
 
 /* ---- CRC-32C ("Crc32Iscsi" of crc-fast 1.8.0; call sites deflated.rs:158-161,
@@ -298,6 +299,34 @@ int no_fetch(size_t n, const int64_t *offset, const int16_t *attributes, const i
 enum { NO_COMPACT_UNCHANGED = 0, NO_COMPACT_REWRITTEN = 1, NO_COMPACT_DELETED = 2 };
 int no_compact_partition(const uint8_t *const *batches, const size_t *lens, size_t n, uint8_t *out,
                          size_t out_cap, uint64_t *out_off, int64_t *removed, int32_t *action);
+
+/* ---- compressed record data: Snappy ----
+ * Compression::inflator, Snappy arm (nisshi-sans-io/src/lib.rs:1717-1751): the whole record data
+ * is one raw Snappy block, after 20 bytes that are skipped when it starts with the xerial magic
+ * "\x82SNAPPY\0" (magic 8, version 4, compatible version 4 and the first chunk's length 4: a stream
+ * of several xerial chunks is not handled by the reference, and so not here).
+ * The raw block is decoded by snap::raw::Decoder::decompress_vec of the `snap` crate (1.1.1 in the
+ * reference's Cargo.lock; the crate is not vendored, so this follows the published format, Snappy's
+ * format_description.txt, with the crate's outcomes: an empty input, a malformed or over-long length
+ * varint, a length beyond u32, an element that reads past the input or writes past the announced
+ * length, a copy with offset 0 or beyond what is written, and a final length that differs from the
+ * announced one all fail).  Returns NO_OK or NO_INFLATE. */
+int no_snappy_raw_len(const uint8_t *in, size_t n, size_t *header_len, uint64_t *len);
+int no_snappy_raw(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+int no_snappy_inflate(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+
+/* A frame with its Snappy batches inflated: every batch of blob in order; one that parses
+ * (no_deflated_parse) with codec 2 (no_compression) and inflates becomes
+ *   its 61 header bytes with batch_length = 49 + inflated length and the codec bits of
+ *   attributes cleared (inflated::Batch::try_from clears them, inflated.rs:123-140; the crc field
+ *   stays the one of the compressed batch, as the inflated batch carries it), then the inflated bytes,
+ * status NO_OK; one that does not inflate is passed through, status NO_INFLATE; every other batch
+ * is passed through with status NO_NONE_DONE.  Decoding the output with no_decode_columns gives
+ * the records Vec<Record>::try_from(deflated::Batch) gives for the inflated batches
+ * (deflated.rs:444-457). */
+enum { NO_NONE_DONE = 10 };
+int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches, uint8_t *out,
+                     size_t out_cap, uint64_t *out_off, int32_t *status);
 
 #ifdef __cplusplus
 }

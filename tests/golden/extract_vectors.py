@@ -253,6 +253,39 @@ def main():
             })
     vec["encode_frames"] = enc
 
+    # -- compressed batches: whole frames with their inflated batches (tests/decode.rs), the three
+    #    producer frames of tests/snappy.rs with what is asserted of their one record, and the bare
+    #    batches of the codec tests in src/record/deflated.rs (one record whose value is LOREM)
+    vec["compressed_frames"] = frame_cases("tests/decode.rs", {"produce_request_v10_002", "produce_request_v10_003"})
+    src = read("tests/snappy.rs")
+    snappy = []
+    for name, line, body in functions(src):
+        arrays = byte_arrays(body)
+        if not arrays:
+            continue
+        asserted = {}
+        for want, what in re.findall(r"assert_eq!\(\s*(\d+)\s*,\s*([\w.()]+)\s*\)", body):
+            asserted[what] = int(want)
+        # an #[ignore]d test is one the reference does not pass: its frame is kept as a case that must fail
+        ignored = re.search(r"#\[ignore\]\s*(?:#\[test\]\s*)?fn\s+" + name + r"\b", src) is not None
+        snappy.append({"name": name, "source": f"nisshi-sans-io/tests/snappy.rs:{line}", "frame": arrays[0],
+                       "ignored": ignored,
+                       "record_count": asserted["deflated.record_count"], "records": asserted["inflated.records.len()"],
+                       "first_record_length": asserted["record.length"]})
+    vec["snappy_frames"] = snappy
+    src = read("src/record/deflated.rs")
+    codecs = []
+    for name, line, body in functions(src):
+        if name in {"decode_gzip", "decode_zstd", "decode_lz4", "decode_snappy"}:
+            arrays = byte_arrays(body)
+            m = re.search(r"vec!\[\s*Record\s*\{", body)
+            q = P(body)
+            q.i = m.start()
+            records = [norm_record(r) for r in q.value()]
+            codecs.append({"name": name, "source": f"nisshi-sans-io/src/record/deflated.rs:{line}",
+                           "batch": arrays[0], "records": records})
+    vec["compressed_batches"] = codecs
+
     # -- criterion bench inputs (benches/decode_bench.rs): bytes only
     bench = []
     src = read("benches/decode_bench.rs")

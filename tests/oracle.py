@@ -81,10 +81,35 @@ def _load():
     lib.no_combine.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int)]
     lib.no_compact_partition.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp]
     lib.no_fetch.argtypes = [sz] + [vp] * 13 + [i64, vp, sz, vp, sz, ctypes.POINTER(sz)]
+    lib.no_snappy_inflate.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
+    lib.no_inflate_frame.argtypes = [vp, vp, sz, vp, sz, vp, vp]
     return lib
 
 
 LIB = _load()
+
+
+def snappy_inflate(data: bytes):
+    """(status, inflated bytes) of the record data of a Snappy batch."""
+    data = bytes(data)
+    out = ctypes.create_string_buffer(max(1, 64 * len(data) + 64))
+    n = ctypes.c_size_t()
+    st = LIB.no_snappy_inflate(data, len(data), out, len(out), ctypes.byref(n))
+    return st, out.raw[:n.value]
+
+
+def inflate_frame(blob, batch_off, out_cap=None):
+    """(status, out bytes, out_off, per-batch status) of a frame with its Snappy batches inflated."""
+    blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+    off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+    n_b = len(off) - 1
+    out_cap = 64 * len(blob) + 64 if out_cap is None else out_cap
+    out = np.zeros(max(out_cap, 1), dtype=np.uint8)
+    out_off = np.zeros(n_b + 1, dtype=np.uint64)
+    status = np.zeros(max(n_b, 1), dtype=np.int32)
+    st = LIB.no_inflate_frame(blob.ctypes.data, off.ctypes.data, n_b, out.ctypes.data, out_cap,
+                              out_off.ctypes.data, status.ctypes.data)
+    return st, out[:int(out_off[n_b])].tobytes() if st == 0 else b"", out_off, status[:n_b]
 
 
 def crc32c(data: bytes) -> int:
