@@ -55,8 +55,9 @@ enum {
     NISSHI_CAPACITY = 7,            /* an output array is too small */
     NISSHI_DEVICE_ERROR = 8,        /* a HIP call failed; see nisshi_hip_last_error */
     NISSHI_INVALID_ARGUMENT = 9,
-    NISSHI_NONE = 10                /* no batch: combine of no batches (Ok(None), nisshi-storage/src/batch.rs:666-668);
-                                       compaction leaves nothing to write for this batch */
+    NISSHI_NONE = 10,               /* no batch: combine of no batches (Ok(None), nisshi-storage/src/batch.rs:666-668);
+                                       compaction leaves nothing to write for this batch; inflate passes this one through */
+    NISSHI_INFLATE = 11             /* the compressed record data does not inflate (the inflator's Error::Snap / Error::Io) */
 };
 
 /* Decoded records are columns, grouped so that the fields the decoder produces
@@ -487,6 +488,40 @@ typedef int (*nisshi_pool_decode_fn)(void *decoder_ctx, const uint8_t *blob, uin
                                      nisshi_totals *totals);
 int nisshi_hip_pool_create_custom(uint32_t n_devices, nisshi_pool_decode_fn decode, void *const *decoder_ctx,
                                   nisshi_hip_pool **pool);
+
+/* ---- compressed batches: Snappy (Compression::inflator, nisshi-sans-io/src/lib.rs:1717-1751, as
+ * called by Vec<Record>::try_from(deflated::Batch), nisshi-sans-io/src/record/deflated.rs:444-457).
+ * The reference inflates a compressed batch's record data and deserializes the records from the
+ * result.  This call rewrites a frame: every batch of d_blob in order; a batch whose header passes
+ * the checks of deflated::Batch::try_from(Bytes) (deflated.rs:108-213), whose codec is Snappy
+ * (attributes & 7 == 2) and whose record data inflates becomes an uncompressed batch -- its 61
+ * header bytes with batch_length = 49 + inflated length and the codec bits of attributes cleared
+ * (inflated::Batch::try_from clears them, inflated.rs:123-140; the crc field stays the compressed
+ * batch's, as the reference's inflated batch carries it: it does not cover the rewritten bytes),
+ * then the inflated record data -- with d_status[b] = NISSHI_OK; one that does not inflate is
+ * passed through as it is, NISSHI_INFLATE; every other batch (uncompressed, another codec, a
+ * header that does not parse) is passed through, NISSHI_NONE.  Decoding the output with
+ * nisshi_hip_decode_dev gives the records the reference gives for the inflated batches.
+ * As in the reference the record data is one raw Snappy block (the `snap` crate's
+ * raw::Decoder::decompress_vec), behind 20 bytes that are skipped when it starts with the xerial
+ * magic "\x82SNAPPY\0": a stream of several xerial chunks does not inflate (the reference's own
+ * test of one is #[ignore]d, nisshi-sans-io/tests/snappy.rs:1163-1166).
+ *
+ * d_out_off receives n_batches + 1 offsets into d_out.  With d_out == NULL the call only sizes:
+ * d_status and d_out_off are filled, totals->out_bytes is the capacity needed.  Otherwise a
+ * d_out of out_cap bytes (16-byte aligned) receives the frame; NISSHI_CAPACITY when it does not
+ * fit (totals->out_bytes says how much is needed).  totals (not NULL: the call waits for the
+ * sizes) has out_bytes and n_failed, the number of batches that did not inflate. */
+int nisshi_hip_inflate_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
+                           const uint64_t *d_batch_off, uint32_t n_batches, uint8_t *d_out,
+                           uint64_t out_cap, uint64_t *d_out_off, int32_t *d_status,
+                           nisshi_totals *totals, void *stream);
+
+/* The same for host buffers: copies in, sizes, inflates, copies out.  out_cap too small:
+ * NISSHI_CAPACITY with totals->out_bytes the capacity needed (out_off and status are filled). */
+int nisshi_hip_inflate(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
+                       const uint64_t *batch_off, uint32_t n_batches, uint8_t *out, uint64_t out_cap,
+                       uint64_t *out_off, int32_t *status, nisshi_totals *totals);
 
 /* Page-locked host memory for the host-buffer entry points: blobs and columns
  * in buffers from here move over PCIe by DMA at link speed; any other host

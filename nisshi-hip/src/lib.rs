@@ -34,6 +34,8 @@ pub enum Status {
     InvalidArgument,
     /// no batch: `Ok(None)` of combine, a batch compaction leaves alone
     None,
+    /// compressed record data that does not inflate: the inflator's `Error::Snap` / `Error::Io`
+    Inflate,
 }
 
 impl From<c_int> for Status {
@@ -49,6 +51,7 @@ impl From<c_int> for Status {
             ffi::NISSHI_CAPACITY => Self::Capacity,
             ffi::NISSHI_INVALID_ARGUMENT => Self::InvalidArgument,
             ffi::NISSHI_NONE => Self::None,
+            ffi::NISSHI_INFLATE => Self::Inflate,
             _ => Self::Device,
         }
     }

@@ -2403,5 +2403,6 @@ __global__ void crc_buffer_finish_kernel(const uint8_t *data, uint64_t len, uint
 #include "storage.inc"
 #include "fetch.inc"
 #include "compact.inc"
+#include "inflate.inc"
 #include "api.inc"
 #include "pool.inc"

@@ -26,7 +26,7 @@ EXPORTS = [
     "nisshi_hip_host_alloc", "nisshi_hip_host_free",
     "nisshi_hip_produce_rows_dev", "nisshi_hip_produce_rows", "nisshi_hip_combine_dev",
     "nisshi_hip_combine", "nisshi_hip_fetch_batches_dev", "nisshi_hip_fetch", "nisshi_hip_builder_fields_dev",
-    "nisshi_hip_compact_dev", "nisshi_hip_compact",
+    "nisshi_hip_compact_dev", "nisshi_hip_compact", "nisshi_hip_inflate_dev", "nisshi_hip_inflate",
     "nisshi_hip_pool_create", "nisshi_hip_pool_create_custom", "nisshi_hip_pool_destroy",
     "nisshi_hip_pool_device_count", "nisshi_hip_pool_device_of", "nisshi_hip_pool_last_error",
     "nisshi_hip_pool_decode",
@@ -48,6 +48,7 @@ ROW_ARRAYS = [("offset", np.int64, 1), ("timestamp", np.int64, 1), ("batch", np.
               ("hdr_offset", np.int64, 2), ("status", np.int32, 0)]
 NO_BATCH = 0xFFFFFFFF
 NONE = 10  # NISSHI_NONE
+INFLATE = 11  # NISSHI_INFLATE
 
 
 class CRows(ctypes.Structure):
@@ -86,7 +87,7 @@ class NisshiError(RuntimeError):
     def __init__(self, status, detail=""):
         self.status = status
         name = C.STATUS_NAMES[status] if 0 <= status < len(C.STATUS_NAMES) else \
-            {8: "DEVICE_ERROR", 9: "INVALID_ARGUMENT", 10: "NONE"}.get(status, str(status))
+            {8: "DEVICE_ERROR", 9: "INVALID_ARGUMENT", 10: "NONE", 11: "INFLATE"}.get(status, str(status))
         super().__init__(f"nisshi_hip: {name} {detail}".strip())
 
 
@@ -153,6 +154,8 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_compact_dev.argtypes = [vp, vp, ctypes.POINTER(C.CColumns), u32, u64, vp,
                                            ctypes.POINTER(C.CColumns), vp, vp, ctypes.POINTER(Totals), vp]
     lib.nisshi_hip_compact.argtypes = [vp, vp, u64, vp, u32, vp, vp, u64, vp, vp, vp, vp, ctypes.POINTER(Totals)]
+    lib.nisshi_hip_inflate_dev.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp, vp, ctypes.POINTER(Totals), vp]
+    lib.nisshi_hip_inflate.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp, vp, ctypes.POINTER(Totals)]
     lib.nisshi_hip_pool_create.argtypes = [vp, u32, ctypes.POINTER(vp)]
     lib.nisshi_hip_pool_create_custom.argtypes = [u32, POOL_DECODE_FN, vp, ctypes.POINTER(vp)]
     lib.nisshi_hip_pool_destroy.argtypes = [vp]
@@ -477,6 +480,46 @@ class Codec:
             d_group.data_ptr() if d_group is not None else None, ctypes.byref(out.c), removed.data_ptr(),
             action.data_ptr(), ctypes.byref(totals) if sync else None, self._stream()))
         return out, removed, action, (totals if sync else None)
+
+    def inflate_dev(self, d_blob, blob_len: int, d_batch_off, n_batches: int):
+        """A frame with its Snappy batches inflated.  Sizes first, then allocates the output:
+        returns (d_out tensor, d_out_off tensor, d_status tensor, totals)."""
+        import torch
+        d_out_off = torch.zeros(n_batches + 1, dtype=torch.int64, device=self.device)
+        d_status = torch.zeros(max(n_batches, 1), dtype=torch.int32, device=self.device)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_inflate_dev(
+            self.ctx, d_blob.data_ptr(), blob_len, d_batch_off.data_ptr(), n_batches, None, 0,
+            d_out_off.data_ptr(), d_status.data_ptr(), ctypes.byref(totals), self._stream()))
+        d_out = torch.zeros(totals.out_bytes + 16, dtype=torch.uint8, device=self.device)
+        again = Totals()
+        self._check(self.lib.nisshi_hip_inflate_dev(
+            self.ctx, d_blob.data_ptr(), blob_len, d_batch_off.data_ptr(), n_batches, d_out.data_ptr(),
+            totals.out_bytes, d_out_off.data_ptr(), d_status.data_ptr(), ctypes.byref(again), self._stream()))
+        return d_out, d_out_off, d_status, totals
+
+    def inflate(self, blob: bytes, batch_off, out_cap: Optional[int] = None):
+        """Host bytes in, host bytes out: (frame bytes, out_off, status np.int32[n], totals).
+        out_cap None: the call is made twice, the first time to learn the size."""
+        arr = np.frombuffer(bytes(blob), dtype=np.uint8)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+        n_b = len(off) - 1
+        out_off = np.zeros(n_b + 1, dtype=np.uint64)
+        status = np.zeros(max(n_b, 1), dtype=np.int32)
+        totals = Totals()
+        cap = 0 if out_cap is None else out_cap
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        st = self.lib.nisshi_hip_inflate(self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data,
+                                         n_b, out.ctypes.data if cap else None, cap, out_off.ctypes.data,
+                                         status.ctypes.data, ctypes.byref(totals))
+        if st == C.CAPACITY and out_cap is None:
+            cap = int(totals.out_bytes)
+            out = np.zeros(max(cap, 1), dtype=np.uint8)
+            st = self.lib.nisshi_hip_inflate(self.ctx, arr.ctypes.data if len(arr) else None, len(arr),
+                                             off.ctypes.data, n_b, out.ctypes.data, cap, out_off.ctypes.data,
+                                             status.ctypes.data, ctypes.byref(totals))
+        self._check(st)
+        return out[:int(totals.out_bytes)].tobytes(), out_off, status[:n_b], totals
 
     def compact(self, blob: bytes, batch_off, group=None, out_cap: Optional[int] = None):
         """Inflate, compact and deflate batches held in host bytes (oldest first).  Returns

@@ -71,9 +71,9 @@ def test_rows_struct_matches_header():
 
 
 def test_status_strings(lib):
-    for st in range(11):
+    for st in range(12):
         assert lib.nisshi_hip_status_str(st) not in (None, b"unknown status")
-    assert lib.nisshi_hip_status_str(11) == b"unknown status"
+    assert lib.nisshi_hip_status_str(12) == b"unknown status"
     assert b"TryGet" in lib.nisshi_hip_status_str(C.TRY_GET)
 
 

@@ -62,7 +62,7 @@ def test_repr_c_structs_have_the_header_s_fields_in_order(rust, c):
 def test_status_constants_and_limits():
     text = gen_ffi.header_text()
     enum = dict(re.findall(r"(NISSHI_[A-Z_]+) = (\d+)", text))
-    assert len(enum) == 11
+    assert len(enum) == 12
     for name, value in enum.items():
         assert re.search(rf"pub const {name}: c_int = {value};", FFI), name
     assert re.search(r"#define NISSHI_STATIC_MAX_BATCHES 16384u", text) and "NISSHI_STATIC_MAX_BATCHES: u32 = 16384;" in FFI
