@@ -330,6 +330,46 @@ impl Codec {
         Ok((out, out_off, totals))
     }
 
+    /// `nisshi_hip_inflate`: the frame with its Snappy batches rewritten as uncompressed ones
+    /// (`Compression::inflator`, lib.rs:1717-1751), every other batch passed through.  Returns the
+    /// frame's bytes, the start of each batch (`n + 1` offsets) and a status a batch: `Ok` inflated,
+    /// `Inflate` the record data does not inflate (passed through), `None` passed through.
+    pub fn inflate(&mut self, blob: &[u8], batch_off: &[u64]) -> Result<(Vec<u8>, Vec<u64>, Vec<Status>, Totals)> {
+        let n = batch_off.len().saturating_sub(1);
+        let mut out_off = vec![0u64; n + 1];
+        let mut status = vec![0i32; n.max(1)];
+        let mut totals = Totals::default();
+        // the first call sizes (NISSHI_CAPACITY and the bytes needed), the second has the room
+        let mut out: Vec<u8> = Vec::new();
+        loop {
+            let st = unsafe {
+                ffi::nisshi_hip_inflate(
+                    self.ctx,
+                    blob.as_ptr(),
+                    blob.len() as u64,
+                    batch_off.as_ptr(),
+                    n as u32,
+                    if out.is_empty() { std::ptr::null_mut() } else { out.as_mut_ptr() },
+                    out.len() as u64,
+                    out_off.as_mut_ptr(),
+                    status.as_mut_ptr(),
+                    &mut totals,
+                )
+            };
+            if st == ffi::NISSHI_CAPACITY && out.is_empty() && totals.out_bytes > 0 {
+                out = vec![0u8; totals.out_bytes as usize];
+                continue;
+            }
+            if st != ffi::NISSHI_OK {
+                return Err(self.fail(st, "nisshi_hip_inflate"));
+            }
+            break;
+        }
+        out.truncate(totals.out_bytes as usize);
+        status.truncate(n);
+        Ok((out, out_off, status.into_iter().map(Status::from).collect(), totals))
+    }
+
     /// The raw context, for the `*_dev` entry points and the storage operators of `ffi`.
     pub fn as_ptr(&mut self) -> *mut ffi::Ctx {
         self.ctx
