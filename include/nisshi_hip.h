@@ -507,18 +507,23 @@ int nisshi_hip_pool_create_custom(uint32_t n_devices, nisshi_pool_decode_fn deco
  * magic "\x82SNAPPY\0": a stream of several xerial chunks does not inflate (the reference's own
  * test of one is #[ignore]d, nisshi-sans-io/tests/snappy.rs:1163-1166).
  *
- * d_out_off receives n_batches + 1 offsets into d_out.  With d_out == NULL the call only sizes:
- * d_status and d_out_off are filled, totals->out_bytes is the capacity needed.  Otherwise a
- * d_out of out_cap bytes (16-byte aligned) receives the frame; NISSHI_CAPACITY when it does not
- * fit (totals->out_bytes says how much is needed).  totals (not NULL: the call waits for the
- * sizes) has out_bytes and n_failed, the number of batches that did not inflate. */
+ * d_out_off receives n_batches + 1 offsets into d_out.  With d_out == NULL the call only says how
+ * much room the output needs: totals->out_bytes is a capacity that holds it whatever the blocks
+ * turn out to be (each batch counted at the larger of its own size and what its block announces;
+ * a block that announces more than 22 bytes a byte of its own cannot inflate and is not counted
+ * so); d_status and d_out_off are not final then.  Otherwise a d_out of out_cap bytes (16-byte
+ * aligned) receives the frame; NISSHI_CAPACITY when out_cap is below that capacity.  The output
+ * is laid out by what the blocks announce and written by one walk over them; only when a block
+ * then does not inflate is it laid out and written a second time, with that batch passed through.
+ * totals (not NULL: the call waits) has out_bytes, the bytes of the frame, and n_failed, the
+ * number of batches that did not inflate. */
 int nisshi_hip_inflate_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
                            const uint64_t *d_batch_off, uint32_t n_batches, uint8_t *d_out,
                            uint64_t out_cap, uint64_t *d_out_off, int32_t *d_status,
                            nisshi_totals *totals, void *stream);
 
-/* The same for host buffers: copies in, sizes, inflates, copies out.  out_cap too small:
- * NISSHI_CAPACITY with totals->out_bytes the capacity needed (out_off and status are filled). */
+/* The same for host buffers: copies in, inflates, copies out.  out_cap below the capacity that the
+ * device form asks for: NISSHI_CAPACITY, with totals->out_bytes that capacity. */
 int nisshi_hip_inflate(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
                        const uint64_t *batch_off, uint32_t n_batches, uint8_t *out, uint64_t out_cap,
                        uint64_t *out_off, int32_t *status, nisshi_totals *totals);

@@ -482,20 +482,24 @@ class Codec:
         return out, removed, action, (totals if sync else None)
 
     def inflate_dev(self, d_blob, blob_len: int, d_batch_off, n_batches: int):
-        """A frame with its Snappy batches inflated.  Sizes first, then allocates the output:
+        """A frame with its Snappy batches inflated.  Asks for the room first, then allocates the output:
         returns (d_out tensor, d_out_off tensor, d_status tensor, totals)."""
         import torch
         d_out_off = torch.zeros(n_batches + 1, dtype=torch.int64, device=self.device)
         d_status = torch.zeros(max(n_batches, 1), dtype=torch.int32, device=self.device)
-        totals = Totals()
+        room = Totals()
         self._check(self.lib.nisshi_hip_inflate_dev(
             self.ctx, d_blob.data_ptr(), blob_len, d_batch_off.data_ptr(), n_batches, None, 0,
-            d_out_off.data_ptr(), d_status.data_ptr(), ctypes.byref(totals), self._stream()))
-        d_out = torch.zeros(totals.out_bytes + 16, dtype=torch.uint8, device=self.device)
-        again = Totals()
+            d_out_off.data_ptr(), d_status.data_ptr(), ctypes.byref(room), self._stream()))
+        d_out = torch.empty(room.out_bytes + 16, dtype=torch.uint8, device=self.device)
+        return self.inflate_into(d_blob, blob_len, d_batch_off, n_batches, d_out, room.out_bytes, d_out_off, d_status)
+
+    def inflate_into(self, d_blob, blob_len, d_batch_off, n_batches, d_out, out_cap, d_out_off, d_status):
+        """nisshi_hip_inflate_dev into buffers the caller holds."""
+        totals = Totals()
         self._check(self.lib.nisshi_hip_inflate_dev(
             self.ctx, d_blob.data_ptr(), blob_len, d_batch_off.data_ptr(), n_batches, d_out.data_ptr(),
-            totals.out_bytes, d_out_off.data_ptr(), d_status.data_ptr(), ctypes.byref(again), self._stream()))
+            out_cap, d_out_off.data_ptr(), d_status.data_ptr(), ctypes.byref(totals), self._stream()))
         return d_out, d_out_off, d_status, totals
 
     def inflate(self, blob: bytes, batch_off, out_cap: Optional[int] = None):
