@@ -1265,6 +1265,178 @@ int no_snappy_inflate(const uint8_t *in, size_t n, uint8_t *out, size_t cap, siz
     return no_snappy_raw(in, n, out, cap, out_len);
 }
 
+/* ------------------------------------------------------------------ LZ4 */
+
+static uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+static uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+/* XXH32 (xxhash's published algorithm) */
+uint32_t no_xxh32(const uint8_t *p, size_t len, uint32_t seed) {
+    const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    const uint8_t *end = p + len;
+    uint32_t h;
+    if (len >= 16) {
+        uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 = rotl32(v1 + le32(p) * P2, 13) * P1;
+            v2 = rotl32(v2 + le32(p + 4) * P2, 13) * P1;
+            v3 = rotl32(v3 + le32(p + 8) * P2, 13) * P1;
+            v4 = rotl32(v4 + le32(p + 12) * P2, 13) * P1;
+            p += 16;
+        } while (p + 16 <= end);
+        h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint32_t)len;
+    while (p + 4 <= end) {
+        h = rotl32(h + le32(p) * P3, 17) * P4;
+        p += 4;
+    }
+    while (p < end) {
+        h = rotl32(h + (*p) * P5, 11) * P1;
+        p++;
+    }
+    h ^= h >> 15;
+    h *= P2;
+    h ^= h >> 13;
+    h *= P3;
+    h ^= h >> 16;
+    return h;
+}
+
+/* One block of the LZ4 block format into out[d ..), which may copy from out[low .. d): LZ4_decompress_safe's
+ * outcomes for a block decoded into room for block_max bytes (what LZ4F_decompress gives it).  A sequence is a
+ * token, the literals' length (15: more bytes follow, each added, until one is not 255), the literals, and
+ * unless the block ends there an offset of two bytes and the match length (15: likewise; four more than
+ * written).  liblz4's checks: a sequence with a match has eight bytes of input and more behind its literals
+ * and twelve bytes of room and more; otherwise it is the last, and its literals end the block exactly; the
+ * bytes of a match length leave four bytes of input behind them; the offset is neither 0 nor beyond out[low];
+ * a match ends five bytes and more before the end of the room. */
+static int lz4_block(const uint8_t *in, size_t n, uint8_t *out, size_t low, size_t *d_io, size_t room_end) {
+    size_t s = 0, d = *d_io;
+    if (n == 0) return NO_INFLATE;
+    for (;;) {
+        if (s >= n) return NO_INFLATE;
+        uint8_t token = in[s++];
+        size_t len = token >> 4;
+        if (len == 15) {
+            uint8_t b;
+            do {
+                if (s >= n) return NO_INFLATE;
+                b = in[s++];
+                len += b;
+            } while (b == 255);
+        }
+        if (len > n - s || len > room_end - d) return NO_INFLATE;
+        if ((n - s - len) < 8 || (room_end - d - len) < 12) {
+            if (s + len != n) return NO_INFLATE; /* (the block's last sequence: literals to its very end) */
+            memcpy(out + d, in + s, len);
+            d += len;
+            break;
+        }
+        memcpy(out + d, in + s, len);
+        s += len;
+        d += len;
+        size_t offset = (size_t)in[s] | (size_t)in[s + 1] << 8;
+        s += 2;
+        size_t mlen = token & 15;
+        if (mlen == 15) {
+            uint8_t b;
+            do {
+                b = in[s++]; /* (eight bytes and more were left: this one is there) */
+                mlen += b;
+                if (s + 4 > n) return NO_INFLATE;
+            } while (b == 255);
+        }
+        mlen += 4;
+        if (offset == 0 || offset > d - low) return NO_INFLATE;
+        if (mlen > room_end - d || room_end - d - mlen < 5) return NO_INFLATE; /* (the last five bytes are literals) */
+        for (size_t i = 0; i < mlen; i++, d++) out[d] = out[d - offset];
+    }
+    *d_io = d;
+    return NO_OK;
+}
+
+/* The frame's descriptor: sets what the flags say; returns the bytes of the header, 0 when it is refused. */
+static size_t lz4_header(const uint8_t *in, size_t n, int *linked, int *block_sums, int *content_sum, int *has_size,
+                         uint64_t *content, size_t *block_max) {
+    if (n < 7 || le32(in) != 0x184D2204u) return 0;
+    uint8_t flg = in[4], bd = in[5];
+    if ((flg >> 6) != 1 || (flg & 2) || (bd & 0x8f) || ((bd >> 4) & 7) < 4) return 0;
+    if (flg & 1) return 0; /* a dictionary id: not handled */
+    *linked = !(flg & 0x20), *block_sums = (flg >> 4) & 1, *has_size = (flg >> 3) & 1, *content_sum = (flg >> 2) & 1;
+    *block_max = (size_t)1 << (8 + 2 * ((bd >> 4) & 7)); /* 4: 64 KiB .. 7: 4 MiB */
+    size_t s = 6;
+    *content = 0;
+    if (*has_size) {
+        if (n < s + 8) return 0;
+        for (int i = 0; i < 8; i++) *content |= (uint64_t)in[s + i] << (8 * i);
+        s += 8;
+    }
+    if (n < s + 1) return 0;
+    if (((no_xxh32(in + 4, s - 4, 0) >> 8) & 0xff) != in[s]) return 0;
+    return s + 1;
+}
+
+/* Room that holds the frame's output whatever its blocks hold: every block at the maximal block size. */
+static size_t lz4_frame_room(const uint8_t *in, size_t n) {
+    int linked, block_sums, content_sum, has_size;
+    uint64_t content;
+    size_t block_max, room = 0;
+    size_t s = lz4_header(in, n, &linked, &block_sums, &content_sum, &has_size, &content, &block_max);
+    if (!s) return 0;
+    while (n >= s + 4) {
+        uint32_t word = le32(in + s);
+        s += 4;
+        if (word == 0) break;
+        size_t size = word & 0x7fffffffu;
+        if (size > block_max || size > n - s) break;
+        room += block_max;
+        s += size + (block_sums ? 4 : 0);
+    }
+    return room;
+}
+
+/* cap: at least lz4_frame_room */
+int no_lz4_frame(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    int linked, block_sums, content_sum, has_size;
+    uint64_t content;
+    size_t block_max;
+    *out_len = 0;
+    size_t s = lz4_header(in, n, &linked, &block_sums, &content_sum, &has_size, &content, &block_max);
+    if (!s) return NO_INFLATE;
+    size_t d = 0;
+    for (;;) {
+        if (n < s + 4) return NO_INFLATE;
+        uint32_t word = le32(in + s);
+        s += 4;
+        if (word == 0) break; /* the end mark */
+        size_t size = word & 0x7fffffffu;
+        if (size > block_max || size > n - s) return NO_INFLATE;
+        if (cap - d < block_max) return NO_CAPACITY;
+        if (word & 0x80000000u) {
+            memcpy(out + d, in + s, size);
+            d += size;
+        } else {
+            size_t low = linked ? (d > 65536 ? d - 65536 : 0) : d;
+            int st = lz4_block(in + s, size, out, low, &d, d + block_max);
+            if (st) return st;
+        }
+        if (block_sums) {
+            if (n < s + size + 4 || no_xxh32(in + s, size, 0) != le32(in + s + size)) return NO_INFLATE;
+            s += 4;
+        }
+        s += size;
+    }
+    if (content_sum) {
+        if (n < s + 4 || no_xxh32(out, d, 0) != le32(in + s)) return NO_INFLATE;
+    }
+    if (has_size && content != d) return NO_INFLATE;
+    *out_len = d;
+    return NO_OK;
+}
+
 int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches, uint8_t *out,
                      size_t out_cap, uint64_t *out_off, int32_t *status) {
     size_t at = 0;
@@ -1276,14 +1448,28 @@ int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_ba
         no_deflated_batch h;
         int st = no_deflated_parse(p, len, &h);
         int codec = 0;
-        if (st == NO_OK && no_compression(h.attributes, &codec) == NO_OK && codec == 2) {
+        if (st == NO_OK && no_compression(h.attributes, &codec) == NO_OK && (codec == 2 || codec == 3)) {
             size_t hl = 0, got = 0;
             uint64_t want = 0;
             const uint8_t *data = h.record_data;
             size_t n = h.record_data_len;
             st = NO_INFLATE;
-            /* the announced length sizes the output before anything is decoded */
-            {
+            if (codec == 3) {
+                /* LZ4: into room of its own first (a frame does not say how long it is) */
+                size_t room = lz4_frame_room(data, n);
+                uint8_t *tmp = (uint8_t *)malloc(room ? room : 1);
+                st = no_lz4_frame(data, n, tmp, room, &got);
+                if (st == NO_OK && 49 + (uint64_t)got > 0x7fffffffull) st = NO_INFLATE;
+                if (st == NO_OK) {
+                    if (at + 61 + got > out_cap) {
+                        free(tmp);
+                        return NO_CAPACITY;
+                    }
+                    memcpy(out + at + 61, tmp, got);
+                }
+                free(tmp);
+            } else {
+                /* Snappy: the announced length sizes the output before anything is decoded */
                 static const uint8_t magic[8] = {0x82, 'S', 'N', 'A', 'P', 'P', 'Y', 0};
                 const uint8_t *raw = data;
                 size_t rn = n;

@@ -315,8 +315,24 @@ int no_snappy_raw_len(const uint8_t *in, size_t n, size_t *header_len, uint64_t 
 int no_snappy_raw(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
 int no_snappy_inflate(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
 
-/* A frame with its Snappy batches inflated: every batch of blob in order; one that parses
- * (no_deflated_parse) with codec 2 (no_compression) and inflates becomes
+/* ---- compressed record data: LZ4 ----
+ * Compression::inflator, Lz4 arm (nisshi-sans-io/src/lib.rs:1752-1755): lz4::Decoder over the record
+ * data, i.e. liblz4's LZ4F_decompress (`lz4` crate 1.28.1 in Cargo.lock, which builds liblz4 from
+ * source; neither is vendored in the reference, so this follows the published LZ4 frame and block
+ * formats, lz4_Frame_format.md and lz4_Block_format.md, with liblz4's checks).  One frame is read:
+ * magic 0x184D2204, FLG (version 01, reserved bit clear), BD (block size 4..7, reserved bits clear),
+ * optional content size and dictionary id, the header checksum (second byte of XXH32 of the
+ * descriptor); blocks of up to the maximal block size, compressed or stored, until the end mark;
+ * block checksums and the content checksum where flagged; the content size where given.  What lies
+ * behind the frame is not looked at (the reference never reads it).
+ * The reference reads the frame lazily, as far as its records need it, so damage behind the last
+ * record's block goes unnoticed there; here the whole frame must be sound (NO_INFLATE otherwise: the
+ * caller takes the reference's own path for that batch).  A frame with a dictionary id is refused. */
+uint32_t no_xxh32(const uint8_t *data, size_t len, uint32_t seed);
+int no_lz4_frame(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+
+/* A frame with its Snappy and LZ4 batches inflated: every batch of blob in order; one that parses
+ * (no_deflated_parse) with codec 2 or 3 (no_compression) and inflates becomes
  *   its 61 header bytes with batch_length = 49 + inflated length and the codec bits of
  *   attributes cleared (inflated::Batch::try_from clears them, inflated.rs:123-140; the crc field
  *   stays the one of the compressed batch, as the inflated batch carries it), then the inflated bytes,

@@ -83,6 +83,9 @@ def _load():
     lib.no_fetch.argtypes = [sz] + [vp] * 13 + [i64, vp, sz, vp, sz, ctypes.POINTER(sz)]
     lib.no_snappy_inflate.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
     lib.no_inflate_frame.argtypes = [vp, vp, sz, vp, sz, vp, vp]
+    lib.no_lz4_frame.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
+    lib.no_xxh32.argtypes = [u8p, sz, ctypes.c_uint32]
+    lib.no_xxh32.restype = ctypes.c_uint32
     return lib
 
 
@@ -98,12 +101,25 @@ def snappy_inflate(data: bytes):
     return st, out.raw[:n.value]
 
 
+def lz4_inflate(data: bytes):
+    """(status, inflated bytes) of the record data of an LZ4 batch (one frame)."""
+    data = bytes(data)
+    out = ctypes.create_string_buffer(max(1, 300 * len(data) + (8 << 20)))
+    n = ctypes.c_size_t()
+    st = LIB.no_lz4_frame(data, len(data), out, len(out), ctypes.byref(n))
+    return st, out.raw[:n.value]
+
+
+def xxh32(data: bytes, seed: int = 0) -> int:
+    return LIB.no_xxh32(bytes(data), len(data), seed)
+
+
 def inflate_frame(blob, batch_off, out_cap=None):
-    """(status, out bytes, out_off, per-batch status) of a frame with its Snappy batches inflated."""
+    """(status, out bytes, out_off, per-batch status) of a frame with its Snappy and LZ4 batches inflated."""
     blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
     off = np.ascontiguousarray(batch_off, dtype=np.uint64)
     n_b = len(off) - 1
-    out_cap = 64 * len(blob) + 64 if out_cap is None else out_cap
+    out_cap = 300 * len(blob) + 64 if out_cap is None else out_cap
     out = np.zeros(max(out_cap, 1), dtype=np.uint8)
     out_off = np.zeros(n_b + 1, dtype=np.uint64)
     status = np.zeros(max(n_b, 1), dtype=np.int32)
