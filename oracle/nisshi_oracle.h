@@ -337,7 +337,7 @@ int no_lz4_frame(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *
  *   attributes cleared (inflated::Batch::try_from clears them, inflated.rs:123-140; the crc field
  *   stays the one of the compressed batch, as the inflated batch carries it), then the inflated bytes,
  * status NO_OK; one that does not inflate is passed through, status NO_INFLATE; every other batch
- * is passed through with status NO_NONE_DONE.  Decoding the output with no_decode_columns gives
+ * (uncompressed, gzip, zstd, a header that does not parse) is passed through with status NO_NONE_DONE.  Decoding the output with no_decode_columns gives
  * the records Vec<Record>::try_from(deflated::Batch) gives for the inflated batches
  * (deflated.rs:444-457). */
 enum { NO_NONE_DONE = 10 };
