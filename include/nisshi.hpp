@@ -70,10 +70,11 @@ struct Error {
         TryFromInt,              // negative batch_length
         UnknownCompressionType,  // detail = attributes & 7
         Malformed,               // the reference panics on this input (codec.rs:70-74, 291-295; record.rs:260)
-        Compressed,              // a compressed batch: not decoded by the device codec
+        Compressed,              // a gzip or zstd batch: not decoded by the device codec
         Capacity,
         Device,
         InvalidArgument,
+        Inflate,                 // Snappy or LZ4 record data that does not inflate (the inflator's Error::Snap / Error::Io)
     } kind;
     int detail;
     std::string message;
@@ -81,6 +82,7 @@ struct Error {
     static Error from_status(int status, int detail = 0) {
         static const Kind kinds[] = {TryGet, TryGet, Overflow, TryFromInt, UnknownCompressionType,
                                      Malformed, Compressed, Capacity, Device, InvalidArgument};
+        if (status == NISSHI_INFLATE) return Error{Inflate, detail, nisshi_hip_status_str(status)};
         return Error{kinds[status >= 1 && status <= 9 ? status : 8], detail, nisshi_hip_status_str(status)};
     }
 };
@@ -482,6 +484,25 @@ inline Result<inflated::Frame> inflate(Codec &codec, const deflated::Frame &fram
         off[b + 1] = blob.size();
         rec_cap += frame.batches[b].record_count;
     }
+    // Snappy and LZ4 batches: the frame with them rewritten as uncompressed batches first
+    // (Compression::inflator, lib.rs:1717-1755, as deflated.rs:444-457 calls it)
+    std::vector<int32_t> inflated_status(nb ? nb : 1, NISSHI_NONE);
+    bool compressed = false;
+    for (const auto &d : frame.batches) compressed = compressed || (d.attributes & 7) == 2 || (d.attributes & 7) == 3;
+    if (compressed) {
+        std::vector<uint64_t> out_off(nb + 1, 0);
+        nisshi_totals room{};
+        int st = nisshi_hip_inflate(codec.ctx(), blob.data(), blob.size(), off.data(), uint32_t(nb), nullptr, 0,
+                                    out_off.data(), inflated_status.data(), &room);
+        if (st && st != NISSHI_CAPACITY) return Error::from_status(st);
+        std::vector<uint8_t> rewritten(room.out_bytes ? room.out_bytes : 1);
+        st = nisshi_hip_inflate(codec.ctx(), blob.data(), blob.size(), off.data(), uint32_t(nb), rewritten.data(),
+                                room.out_bytes, out_off.data(), inflated_status.data(), &room);
+        if (st) return Error::from_status(st);
+        rewritten.resize(room.out_bytes);
+        blob.swap(rewritten);
+        off.swap(out_off);
+    }
     // a record is at least seven bytes, a header at least two
     if (rec_cap > blob.size() / 7 + 1) rec_cap = blob.size() / 7 + 1;
     // (a batch that ends on the sequential walk takes its header slots twice)
@@ -497,14 +518,19 @@ inline Result<inflated::Frame> inflate(Codec &codec, const deflated::Frame &fram
     for (size_t b = 0; b < nb; b++) {
         const deflated::Batch &d = frame.batches[b];
         // the first failing batch is the frame's error (collect::<Result<Vec<_>>>)
+        if (inflated_status[b] == NISSHI_INFLATE) return Error::from_status(NISSHI_INFLATE, d.attributes & 7);
         if (cols.status[b]) return Error::from_status(cols.status[b], d.attributes & 7);
+        // an inflated batch: its records lie in the rewritten frame; batch_length and, by reference,
+        // attributes are the compressed batch's (inflated.rs:114-187 copies them from the deflated batch)
+        bool was_inflated = inflated_status[b] == NISSHI_OK;
+        Bytes record_data = was_inflated ? Bytes(blob.data() + off[b] + 61, size_t(off[b + 1] - off[b] - 61)) : d.record_data;
         inflated::Batch ib;
         ib.base_offset = cols.base_offset[b];
-        ib.batch_length = cols.batch_length[b];
+        ib.batch_length = was_inflated ? d.batch_length : cols.batch_length[b];
         ib.partition_leader_epoch = cols.partition_leader_epoch[b];
         ib.magic = cols.magic[b];
         ib.crc = cols.crc[b];
-        ib.attributes = cols.attributes[b];
+        ib.attributes = was_inflated && !by_value ? d.attributes : cols.attributes[b];
         ib.last_offset_delta = cols.last_offset_delta[b];
         ib.base_timestamp = cols.base_timestamp[b];
         ib.max_timestamp = cols.max_timestamp[b];
@@ -518,12 +544,12 @@ inline Result<inflated::Frame> inflate(Codec &codec, const deflated::Frame &fram
             rec.attributes = cols.rattributes[r];
             rec.timestamp_delta = cols.timestamp_delta[r];
             rec.offset_delta = cols.rkey[r].offset_delta;
-            rec.key = span(d.record_data, cols.rkey[r].key_off, cols.rkey[r].key_len);
-            rec.value = span(d.record_data, cols.rval[r].val_off, cols.rval[r].val_len);
+            rec.key = span(record_data, cols.rkey[r].key_off, cols.rkey[r].key_len);
+            rec.value = span(record_data, cols.rval[r].val_off, cols.rval[r].val_len);
             rec.headers.reserve(size_t(cols.rval[r].hdr_count));
             for (uint32_t h = cols.rval[r].hdr_base; h < cols.rval[r].hdr_base + uint32_t(cols.rval[r].hdr_count); h++)
-                rec.headers.push_back(Header{span(d.record_data, cols.hdr[h].key_off, cols.hdr[h].key_len),
-                                             span(d.record_data, cols.hdr[h].val_off, cols.hdr[h].val_len)});
+                rec.headers.push_back(Header{span(record_data, cols.hdr[h].key_off, cols.hdr[h].key_len),
+                                             span(record_data, cols.hdr[h].val_off, cols.hdr[h].val_len)});
             ib.records.push_back(std::move(rec));
         }
         out.batches.push_back(std::move(ib));

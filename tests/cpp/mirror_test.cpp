@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <string>
 
+#include "compressed_vectors.h"
 #include "nisshi.hpp"
 
 using namespace nisshi;
@@ -100,9 +101,50 @@ static void attributes_by_value_and_by_reference(Codec &codec) {
     d.attributes = 5;  // no such compression
     auto bad = inflated::Batch::try_from(codec, d);
     CHECK(bad.is_err() && bad.error().kind == Error::UnknownCompressionType && bad.error().detail == 5);
-    d.attributes = 3;  // lz4: not decoded on the device
+    d.attributes = 1;  // gzip: not decoded on the device
     bad = inflated::Batch::try_from(codec, d);
     CHECK(bad.is_err() && bad.error().kind == Error::Compressed);
+    d.attributes = 3;  // lz4, which these ten bytes are not a frame of
+    bad = inflated::Batch::try_from(codec, d);
+    CHECK(bad.is_err() && bad.error().kind == Error::Inflate);
+}
+
+// deflated.rs:762-905 (decode_lz4, decode_snappy): a compressed batch of one record whose value is LOREM;
+// deflated.rs:589-760 (decode_gzip, decode_zstd) stay with the reference's own code.
+static void inflate_compressed_batches(Codec &codec) {
+    struct Case { const uint8_t *bytes; size_t len; int codec; };
+    const Case cases[] = {{kSnappyBatch, sizeof(kSnappyBatch), 2}, {kLz4Batch, sizeof(kLz4Batch), 3}};
+    for (const Case &k : cases) {
+        auto d = deflated::Batch::try_from(Bytes(k.bytes, k.len)).unwrap();
+        CHECK((d.attributes & 7) == k.codec && d.record_count == 1);
+        auto by_val = inflated::Batch::try_from(codec, deflated::Batch(d));
+        CHECK(by_val.is_ok());
+        CHECK((by_val->attributes & 7) == 0 && by_val->records.size() == 1);
+        // (the inflated batch carries the compressed batch's batch_length and crc, inflated.rs:114-150)
+        CHECK(by_val->batch_length == d.batch_length && by_val->crc == d.crc && by_val->base_timestamp == d.base_timestamp);
+        const Record &rec = by_val->records[0];
+        CHECK(rec.length == kLoremRecordLength && rec.attributes == 0 && rec.timestamp_delta == 0 && rec.offset_delta == 0);
+        CHECK(!rec.key.has_value() && rec.value.has_value() && *rec.value == Bytes(kLorem, sizeof(kLorem)) && rec.headers.empty());
+        auto by_ref = inflated::Batch::try_from(codec, d);
+        CHECK(by_ref.is_ok() && by_ref->attributes == d.attributes && by_ref->records == by_val->records);
+        // a frame of the compressed batch between two plain ones: the others are untouched
+        deflated::Frame frame;
+        frame.batches.push_back(deflated::Batch::try_from(Bytes(kBatch71, sizeof(kBatch71))).unwrap());
+        frame.batches.push_back(d);
+        frame.batches.push_back(frame.batches[0]);
+        auto all = inflated::Frame::try_from(codec, frame);
+        CHECK(all.is_ok() && all->batches.size() == 3 && all->batches[1].records == by_val->records);
+        CHECK(all->batches[0].records.size() == 1 && all->batches[0] == all->batches[2]);
+        // the stream cut short: the inflator's error
+        deflated::Batch cut = d;
+        cut.record_data = d.record_data.slice(0, d.record_data.len() - 9);
+        cut.batch_length -= 9;
+        auto bad = inflated::Batch::try_from(codec, cut);
+        CHECK(bad.is_err() && bad.error().kind == Error::Inflate && bad.error().detail == k.codec);
+    }
+    auto gz = deflated::Batch::try_from(Bytes(kGzipBatch, sizeof(kGzipBatch))).unwrap();
+    auto bad = inflated::Batch::try_from(codec, gz);
+    CHECK(bad.is_err() && bad.error().kind == Error::Compressed && bad.error().detail == 1);
 }
 
 static void records_with_keys_and_headers_round_trip(Codec &codec) {
@@ -447,6 +489,7 @@ int main(int argc, char **argv) {
         Codec codec(0);
         inflate_batch(codec);
         attributes_by_value_and_by_reference(codec);
+        inflate_compressed_batches(codec);
         records_with_keys_and_headers_round_trip(codec);
         truncated_record_data_is_an_error(codec);
         combine_empty(codec);
