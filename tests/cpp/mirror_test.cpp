@@ -416,8 +416,8 @@ static void builder_sizes() {
     CHECK(b.producer_epoch == 0 && b.base_sequence == 0 && b.partition_leader_epoch == -1 && b.magic == 2 &&
           b.producer_id == -1 && b.max_timestamp == b.base_timestamp && b.base_timestamp > 1600000000000);
     CHECK(std::move(b).record(rb).size_in_bytes() == 59);
-    // a body of 64..127 bytes: two bytes of zigzag prefix on the wire, one counted (Q8 of the survey of quirks:
-    // Sequence::size_in_bytes uses the unsigned varint's size, codec.rs:482-491)
+    // a body of 64..127 bytes: two bytes of zigzag prefix on the wire, one counted
+    // (Sequence::size_in_bytes uses the unsigned varint's size, codec.rs:482-491)
     std::vector<uint8_t> v70(70, 7);
     record::Builder wide = record::Builder().value(Bytes(v70.data(), v70.size()));
     CHECK(wide.size_in_bytes() == 1 + 1 + 1 + 1 + 2 + 70 + 1);
