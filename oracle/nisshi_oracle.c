@@ -1437,6 +1437,230 @@ int no_lz4_frame(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *
     return NO_OK;
 }
 
+/* ------------------------------------------------------------------ gzip */
+
+/* DEFLATE's bits come lowest bit of a byte first (RFC 1951, 3.1.1) */
+typedef struct {
+    const uint8_t *in;
+    size_t n, pos;
+    uint64_t hold;
+    int bits;
+    uint8_t *out;
+    size_t cap, d;
+} zstream;
+
+static int zneed(zstream *z, int need) { /* 0 when `need` bits (up to 32) are in hold */
+    while (z->bits < need) {
+        if (z->pos >= z->n) return -1;
+        z->hold |= (uint64_t)z->in[z->pos++] << z->bits;
+        z->bits += 8;
+    }
+    return 0;
+}
+
+static int zbits(zstream *z, int need, uint32_t *v) {
+    if (zneed(z, need)) return -1;
+    *v = (uint32_t)(z->hold & ((1ull << need) - 1));
+    z->hold >>= need;
+    z->bits -= need;
+    return 0;
+}
+
+/* A canonical Huffman code (RFC 1951, 3.2.2): count[len] codes of each length, the symbols in the order of
+ * their codes.  Returns 0 for a complete set of lengths, a negative number for an over-subscribed one, a
+ * positive number for an incomplete one. */
+typedef struct {
+    uint16_t count[16], symbol[288];
+} zcode;
+
+static int zconstruct(zcode *h, const uint16_t *length, int n) {
+    uint16_t offs[16];
+    for (int len = 0; len <= 15; len++) h->count[len] = 0;
+    for (int i = 0; i < n; i++) h->count[length[i]]++;
+    int left = 1;
+    for (int len = 1; len <= 15; len++) {
+        left <<= 1;
+        left -= h->count[len];
+        if (left < 0) return left;
+    }
+    offs[1] = 0;
+    for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + h->count[len]);
+    for (int i = 0; i < n; i++)
+        if (length[i]) h->symbol[offs[length[i]]++] = (uint16_t)i;
+    return left;
+}
+
+/* the next symbol: a code's bits come highest first; -1 out of input, -2 no such code */
+static int zdecode(zstream *z, const zcode *h) {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; len++) {
+        uint32_t bit;
+        if (zbits(z, 1, &bit)) return -1;
+        code |= (int)bit;
+        int count = h->count[len];
+        if (code - count < first) return h->symbol[index + (code - first)];
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -2;
+}
+
+static int zcodes(zstream *z, const zcode *lencode, const zcode *distcode) {
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (;;) {
+        int sym = zdecode(z, lencode);
+        if (sym < 0) return NO_INFLATE;
+        if (sym < 256) {
+            if (z->d >= z->cap) return NO_INFLATE;
+            z->out[z->d++] = (uint8_t)sym;
+        } else if (sym == 256) {
+            return NO_OK;
+        } else {
+            sym -= 257;
+            if (sym >= 29) return NO_INFLATE;
+            uint32_t extra;
+            if (zbits(z, lext[sym], &extra)) return NO_INFLATE;
+            size_t len = lbase[sym] + extra;
+            int ds = zdecode(z, distcode);
+            if (ds < 0 || ds >= 30) return NO_INFLATE;
+            if (zbits(z, dext[ds], &extra)) return NO_INFLATE;
+            size_t dist = dbase[ds] + extra;
+            if (dist > z->d) return NO_INFLATE;
+            if (len > z->cap - z->d) return NO_INFLATE;
+            for (size_t i = 0; i < len; i++, z->d++) z->out[z->d] = z->out[z->d - dist];
+        }
+    }
+}
+
+/* RFC 1951 over in[pos ..): the blocks up to the final one.  cap: the bytes the member says it holds. */
+static int zinflate(zstream *z) {
+    for (;;) {
+        uint32_t last, type;
+        if (zbits(z, 1, &last) || zbits(z, 2, &type)) return NO_INFLATE;
+        if (type == 0) {
+            /* stored: the rest of the byte is dropped, LEN and its complement, LEN bytes */
+            z->hold = 0;
+            z->bits = 0;
+            if (z->n - z->pos < 4) return NO_INFLATE;
+            uint32_t len = (uint32_t)z->in[z->pos] | (uint32_t)z->in[z->pos + 1] << 8;
+            uint32_t nlen = (uint32_t)z->in[z->pos + 2] | (uint32_t)z->in[z->pos + 3] << 8;
+            if ((len ^ 0xffffu) != nlen) return NO_INFLATE;
+            z->pos += 4;
+            if (z->n - z->pos < len || z->cap - z->d < len) return NO_INFLATE;
+            memcpy(z->out + z->d, z->in + z->pos, len);
+            z->pos += len;
+            z->d += len;
+        } else if (type == 1) {
+            zcode lencode, distcode;
+            uint16_t lengths[288];
+            int i = 0;
+            for (; i < 144; i++) lengths[i] = 8;
+            for (; i < 256; i++) lengths[i] = 9;
+            for (; i < 280; i++) lengths[i] = 7;
+            for (; i < 288; i++) lengths[i] = 8;
+            zconstruct(&lencode, lengths, 288);
+            for (i = 0; i < 30; i++) lengths[i] = 5;
+            zconstruct(&distcode, lengths, 30);
+            int st = zcodes(z, &lencode, &distcode);
+            if (st) return st;
+        } else if (type == 2) {
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint32_t nlen, ndist, ncode;
+            if (zbits(z, 5, &nlen) || zbits(z, 5, &ndist) || zbits(z, 4, &ncode)) return NO_INFLATE;
+            nlen += 257, ndist += 1, ncode += 4;
+            if (nlen > 286 || ndist > 30) return NO_INFLATE;
+            uint16_t lengths[320];
+            zcode lencode, distcode;
+            uint32_t i;
+            for (i = 0; i < ncode; i++) {
+                uint32_t v;
+                if (zbits(z, 3, &v)) return NO_INFLATE;
+                lengths[order[i]] = (uint16_t)v;
+            }
+            for (; i < 19; i++) lengths[order[i]] = 0;
+            if (zconstruct(&lencode, lengths, 19) != 0) return NO_INFLATE; /* (the code of the code lengths: complete) */
+            uint32_t index = 0;
+            while (index < nlen + ndist) {
+                int sym = zdecode(z, &lencode);
+                if (sym < 0) return NO_INFLATE;
+                if (sym < 16) {
+                    lengths[index++] = (uint16_t)sym;
+                } else {
+                    uint32_t len = 0, rep;
+                    if (sym == 16) {
+                        if (index == 0) return NO_INFLATE;
+                        len = lengths[index - 1];
+                        if (zbits(z, 2, &rep)) return NO_INFLATE;
+                        rep += 3;
+                    } else if (sym == 17) {
+                        if (zbits(z, 3, &rep)) return NO_INFLATE;
+                        rep += 3;
+                    } else {
+                        if (zbits(z, 7, &rep)) return NO_INFLATE;
+                        rep += 11;
+                    }
+                    if (index + rep > nlen + ndist) return NO_INFLATE;
+                    while (rep--) lengths[index++] = (uint16_t)len;
+                }
+            }
+            if (lengths[256] == 0) return NO_INFLATE; /* no end of block */
+            if (zconstruct(&lencode, lengths, (int)nlen) != 0) return NO_INFLATE;
+            int left = zconstruct(&distcode, lengths + nlen, (int)ndist);
+            /* (a distance code of one single code, of one bit, is the one incomplete set in use) */
+            if (left < 0 || (left > 0 && !(distcode.count[1] == 1 && distcode.count[0] == ndist - 1))) return NO_INFLATE;
+            int st = zcodes(z, &lencode, &distcode);
+            if (st) return st;
+        } else {
+            return NO_INFLATE;
+        }
+        if (last) return NO_OK;
+    }
+}
+
+/* The header of a gzip member (RFC 1952, 2.3): the bytes it takes, 0 when it is refused. */
+static size_t gzip_header(const uint8_t *in, size_t n) {
+    if (n < 18 || in[0] != 0x1f || in[1] != 0x8b || in[2] != 8) return 0;
+    uint8_t flg = in[3];
+    if (flg & 0xe2) return 0; /* reserved bits, or a header checksum */
+    size_t s = 10;
+    if (flg & 4) {
+        if (n < s + 2) return 0;
+        size_t xlen = (size_t)in[s] | (size_t)in[s + 1] << 8;
+        s += 2;
+        if (n - s < xlen) return 0;
+        s += xlen;
+    }
+    for (int field = 0; field < 2; field++) {
+        if (flg & (field ? 16 : 8)) {
+            while (s < n && in[s]) s++;
+            if (s >= n) return 0;
+            s++;
+        }
+    }
+    return n - s >= 8 ? s : 0;
+}
+
+/* cap: at least the member's length field (its last four bytes) */
+int no_gzip_member(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    *out_len = 0;
+    size_t s = gzip_header(in, n);
+    if (!s) return NO_INFLATE;
+    uint32_t isize = le32(in + n - 4);
+    if (isize > cap) return NO_CAPACITY;
+    zstream z = {in, n - 8, s, 0, 0, out, isize, 0};
+    int st = zinflate(&z);
+    if (st) return st;
+    /* the trailer follows the last block's last byte, and ends the data */
+    if (z.pos != n - 8 || z.d != isize) return NO_INFLATE;
+    *out_len = z.d;
+    return NO_OK;
+}
+
 int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches, uint8_t *out,
                      size_t out_cap, uint64_t *out_off, int32_t *status) {
     size_t at = 0;
@@ -1448,13 +1672,20 @@ int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_ba
         no_deflated_batch h;
         int st = no_deflated_parse(p, len, &h);
         int codec = 0;
-        if (st == NO_OK && no_compression(h.attributes, &codec) == NO_OK && (codec == 2 || codec == 3)) {
+        if (st == NO_OK && no_compression(h.attributes, &codec) == NO_OK && codec >= 1 && codec <= 3) {
             size_t hl = 0, got = 0;
             uint64_t want = 0;
             const uint8_t *data = h.record_data;
             size_t n = h.record_data_len;
             st = NO_INFLATE;
-            if (codec == 3) {
+            if (codec == 1) {
+                /* gzip: the member's last four bytes say how long it is */
+                if (n >= 18 && 49 + (uint64_t)le32(data + n - 4) <= 0x7fffffffull && (uint64_t)le32(data + n - 4) <= 1032ull * n + 64) {
+                    want = le32(data + n - 4);
+                    if (at + 61 + want > out_cap) return NO_CAPACITY;
+                    st = no_gzip_member(data, n, out + at + 61, (size_t)want, &got);
+                }
+            } else if (codec == 3) {
                 /* LZ4: into room of its own first (a frame does not say how long it is) */
                 size_t room = lz4_frame_room(data, n);
                 uint8_t *tmp = (uint8_t *)malloc(room ? room : 1);

@@ -331,13 +331,25 @@ int no_snappy_inflate(const uint8_t *in, size_t n, uint8_t *out, size_t cap, siz
 uint32_t no_xxh32(const uint8_t *data, size_t len, uint32_t seed);
 int no_lz4_frame(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
 
-/* A frame with its Snappy and LZ4 batches inflated: every batch of blob in order; one that parses
- * (no_deflated_parse) with codec 2 or 3 (no_compression) and inflates becomes
+/* ---- compressed record data: gzip ----
+ * Compression::inflator, Gzip arm (nisshi-sans-io/src/lib.rs:1716): flate2's GzDecoder over the record data
+ * (`flate2` 1.1 in Cargo.lock with its Rust inflate, not vendored: restated from RFC 1952, the gzip member,
+ * and RFC 1951, DEFLATE).  One member is read: the ten-byte header (magic 1f 8b, method 8; the optional
+ * extra field, name and comment are skipped; a header checksum or a reserved flag is refused), DEFLATE blocks
+ * (stored, fixed and dynamic Huffman codes; a set of code lengths must be complete, but for a distance code
+ * of one single code; distances reach no further back than what is written), and the trailer, whose length
+ * field must be the number of bytes inflated and must end the record data.  The trailer's CRC-32 is not
+ * compared: the reference reads the stream as far as its records need it and does not get to the trailer.
+ * As for LZ4: the whole member must be sound here, NO_INFLATE otherwise. */
+int no_gzip_member(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+
+/* A frame with its gzip, Snappy and LZ4 batches inflated: every batch of blob in order; one that parses
+ * (no_deflated_parse) with codec 1, 2 or 3 (no_compression) and inflates becomes
  *   its 61 header bytes with batch_length = 49 + inflated length and the codec bits of
  *   attributes cleared (inflated::Batch::try_from clears them, inflated.rs:123-140; the crc field
  *   stays the one of the compressed batch, as the inflated batch carries it), then the inflated bytes,
  * status NO_OK; one that does not inflate is passed through, status NO_INFLATE; every other batch
- * (uncompressed, gzip, zstd, a header that does not parse) is passed through with status NO_NONE_DONE.  Decoding the output with no_decode_columns gives
+ * (uncompressed, zstd, a header that does not parse) is passed through with status NO_NONE_DONE.  Decoding the output with no_decode_columns gives
  * the records Vec<Record>::try_from(deflated::Batch) gives for the inflated batches
  * (deflated.rs:444-457). */
 enum { NO_NONE_DONE = 10 };

@@ -84,6 +84,7 @@ def _load():
     lib.no_snappy_inflate.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
     lib.no_inflate_frame.argtypes = [vp, vp, sz, vp, sz, vp, vp]
     lib.no_lz4_frame.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
+    lib.no_gzip_member.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
     lib.no_xxh32.argtypes = [u8p, sz, ctypes.c_uint32]
     lib.no_xxh32.restype = ctypes.c_uint32
     return lib
@@ -98,6 +99,15 @@ def snappy_inflate(data: bytes):
     out = ctypes.create_string_buffer(max(1, 64 * len(data) + 64))
     n = ctypes.c_size_t()
     st = LIB.no_snappy_inflate(data, len(data), out, len(out), ctypes.byref(n))
+    return st, out.raw[:n.value]
+
+
+def gzip_inflate(data: bytes):
+    """(status, inflated bytes) of the record data of a gzip batch (one member)."""
+    data = bytes(data)
+    out = ctypes.create_string_buffer(max(1, 1040 * len(data) + 64))
+    n = ctypes.c_size_t()
+    st = LIB.no_gzip_member(data, len(data), out, len(out), ctypes.byref(n))
     return st, out.raw[:n.value]
 
 
@@ -119,7 +129,7 @@ def inflate_frame(blob, batch_off, out_cap=None):
     blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
     off = np.ascontiguousarray(batch_off, dtype=np.uint64)
     n_b = len(off) - 1
-    out_cap = 300 * len(blob) + 64 if out_cap is None else out_cap
+    out_cap = 1040 * len(blob) + 64 if out_cap is None else out_cap
     out = np.zeros(max(out_cap, 1), dtype=np.uint8)
     out_off = np.zeros(n_b + 1, dtype=np.uint64)
     status = np.zeros(max(n_b, 1), dtype=np.int32)
