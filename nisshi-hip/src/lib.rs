@@ -330,8 +330,8 @@ impl Codec {
         Ok((out, out_off, totals))
     }
 
-    /// `nisshi_hip_inflate`: the frame with its Snappy and LZ4 batches rewritten as uncompressed
-    /// ones (`Compression::inflator`, lib.rs:1717-1755), every other batch passed through.  Returns the
+    /// `nisshi_hip_inflate`: the frame with its gzip, Snappy and LZ4 batches rewritten as uncompressed
+    /// ones (`Compression::inflator`, lib.rs:1716-1755), every other batch passed through.  Returns the
     /// frame's bytes, the start of each batch (`n + 1` offsets) and a status a batch: `Ok` inflated,
     /// `Inflate` the record data does not inflate (passed through), `None` passed through.
     pub fn inflate(&mut self, blob: &[u8], batch_off: &[u64]) -> Result<(Vec<u8>, Vec<u64>, Vec<Status>, Totals)> {

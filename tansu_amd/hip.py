@@ -482,7 +482,7 @@ class Codec:
         return out, removed, action, (totals if sync else None)
 
     def inflate_dev(self, d_blob, blob_len: int, d_batch_off, n_batches: int):
-        """A frame with its Snappy and LZ4 batches inflated.  Asks for the room first, then allocates the output:
+        """A frame with its gzip, Snappy and LZ4 batches inflated.  Asks for the room first, then allocates the output:
         returns (d_out tensor, d_out_off tensor, d_status tensor, totals)."""
         import torch
         d_out_off = torch.zeros(n_batches + 1, dtype=torch.int64, device=self.device)

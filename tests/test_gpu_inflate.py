@@ -75,9 +75,9 @@ def test_reference_vectors(codec):
 
 def test_mixed_frame_and_streams_that_do_not_inflate(codec):
     plain = build_batch(dict(base_offset=3), [C.Record(0, 0, 0, 0, b"k", b"v")])
-    gz = bytes([c for c in V["compressed_batches"] if c["name"] == "decode_gzip"][0]["batch"])
+    zs = bytes([c for c in V["compressed_batches"] if c["name"] == "decode_zstd"][0]["batch"])
     good = snappy_batch(build_batch(dict(base_offset=9), [C.Record(0, 0, i, i, b"key%d" % i, b"value" * i) for i in range(40)]))
-    batches = [plain, good, gz, plain[:30], snappy_batch(plain, xerial=True)]
+    batches = [plain, good, zs, plain[:30], snappy_batch(plain, xerial=True)]
     for name, stream in corrupt_cases().items():
         head = bytearray(good[:61])
         struct.pack_into(">i", head, 8, 49 + len(stream))

@@ -85,8 +85,8 @@ def test_length_bytes_and_overlaps(codec):
 
 def test_frames_that_do_not_inflate_and_a_mixed_frame(codec):
     plain = build_batch(dict(base_offset=3), [C.Record(0, 0, i, i, b"key%d" % i, b"value" * i) for i in range(40)])
-    gz = bytes([c for c in V["compressed_batches"] if c["name"] == "decode_gzip"][0]["batch"])
-    batches = [plain, lz4_batch(plain), gz, snappy_batch(plain), plain[:30], lz4_batch(plain, linked=True, content_sum=True)]
+    zs = bytes([c for c in V["compressed_batches"] if c["name"] == "decode_zstd"][0]["batch"])
+    batches = [plain, lz4_batch(plain), zs, snappy_batch(plain), plain[:30], lz4_batch(plain, linked=True, content_sum=True)]
     names = []
     for name, f in lz4_cases.corrupt_cases().items():
         batches.append(framed_batch(plain, f))

@@ -97,14 +97,14 @@ def test_frame_with_other_batches_passes_them_through():
     from util import build_batch
     plain = build_batch(dict(base_offset=3), [C.Record(0, 0, 0, 0, b"k", b"v")])
     case = [c for c in V["compressed_batches"] if c["name"] == "decode_snappy"][0]
-    gz = bytes([c for c in V["compressed_batches"] if c["name"] == "decode_gzip"][0]["batch"])
+    zs = bytes([c for c in V["compressed_batches"] if c["name"] == "decode_zstd"][0]["batch"])
     snappy = bytes(case["batch"])
     broken = bytearray(snappy)
     broken[61] += 1                                      # announces a byte more than the stream holds
-    batches = [plain, snappy, gz, bytes(broken), plain[:30]]
+    batches = [plain, snappy, zs, bytes(broken), plain[:30]]
     st, out, out_off, status = oracle.inflate_frame(b"".join(batches), offsets_of(batches))
     assert st == C.OK
     assert list(status) == [10, C.OK, 10, INFLATE, 10]
     pieces = [out[int(out_off[i]):int(out_off[i + 1])] for i in range(5)]
-    assert pieces[0] == plain and pieces[2] == gz and pieces[3] == bytes(broken) and pieces[4] == plain[:30]
+    assert pieces[0] == plain and pieces[2] == zs and pieces[3] == bytes(broken) and pieces[4] == plain[:30]
     assert len(pieces[1]) == 61 + 454

@@ -1,6 +1,7 @@
 """Kernel times of the inflate: one batch of a thousand small records (keys, values of words, two headers)
 compressed on the host and repeated COUNT times (8192 by default).  CODEC=lz4 in the environment: an LZ4 frame
-(independent blocks of 64 KiB, no checksums: what Kafka's clients write) instead of a Snappy block.
+(independent blocks of 64 KiB, no checksums: what Kafka's clients write) instead of a Snappy block; CODEC=gzip: a
+gzip member from zlib at its default level.
 python tools/inflate_time.py [COUNT]"""
 import json, os, struct, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -21,15 +22,18 @@ for i in range(1000):
     headers = [C.Header(b"trace", bytes(rng.integers(0, 256, 8, dtype=np.uint8))), C.Header(b"kind", words[i % 8])]
     records.append(C.Record(0, 0, i, i, b"user-%06d" % int(rng.integers(0, 5000)), value, headers))
 plain = build_batch(dict(base_offset=0, last_offset_delta=999), records)
-lz4 = os.environ.get("CODEC") == "lz4"
-if lz4:
+lz4 = os.environ.get("CODEC") in ("lz4", "gzip")    # (below: no count of elements)
+if os.environ.get("CODEC") == "gzip":
+    import gzip_cases
+    data = gzip_cases.member(plain[61:])
+elif lz4:
     import lz4_cases
     data = lz4_cases.frame(plain[61:])
 else:
     data = compress(plain[61:], window=65535)   # (as far back as a Snappy compressor's 64 KiB blocks reach)
 head = bytearray(plain[:61])
 struct.pack_into(">i", head, 8, 49 + len(data))
-struct.pack_into(">h", head, 21, 3 if lz4 else 2)
+struct.pack_into(">h", head, 21, {"gzip": 1, "lz4": 3}.get(os.environ.get("CODEC"), 2))
 struct.pack_into(">I", head, 17, oracle.crc32c(bytes(head[21:]) + data))
 batch = bytes(head) + data
 # elements of the stream
@@ -74,6 +78,6 @@ st, out, out_off, status = oracle.inflate_frame(blob[:sample * len(batch)], off[
 cpu_s = time.perf_counter() - t0
 assert st == 0 and len(out) == sample * len(plain)
 print(json.dumps({"cpu_one_core_gbs_out": round(len(out) / cpu_s / 1e9, 3), "batches": count, "compressed_bytes": len(blob), "inflated_bytes": int(totals.out_bytes),
-                  "codec": "lz4" if lz4 else "snappy", "elements_a_batch": n_elem or None,
+                  "codec": os.environ.get("CODEC", "snappy"), "elements_a_batch": n_elem or None,
                   "bytes_an_element": round((len(plain) - 61) / n_elem, 1) if n_elem else None, "kernels_ms": res,
                   "write_gbs_out": round(totals.out_bytes / write / 1e6, 1) if write else None}))
