@@ -521,11 +521,13 @@ int nisshi_hip_pool_create_custom(uint32_t n_devices, nisshi_pool_decode_fn deco
  * d_out_off receives n_batches + 1 offsets into d_out.  With d_out == NULL the call only says how
  * much room the output needs: totals->out_bytes is a capacity that holds it whatever the blocks
  * turn out to be (each batch counted at the larger of its own size and what its Snappy block or
- * gzip member announces or its LZ4 frame, walked for this, holds; a block that announces more than 22 bytes
+ * gzip member announces, an LZ4 batch with its frame's blocks at their maximal size; a block that announces more than 22 bytes
  * a byte of its own cannot inflate and is not counted so); d_status and d_out_off are not final then.  Otherwise a d_out of out_cap bytes (16-byte
  * aligned) receives the frame; NISSHI_CAPACITY when out_cap is below that capacity.  The output
- * is laid out by what the blocks announce and written by one walk over them; only when a block
- * then does not inflate is it laid out and written a second time, with that batch passed through.
+ * is laid out by what the blocks announce and written by one walk over them (LZ4 frames, which
+ * announce nothing, are walked into a scratch area of the context first and copied from there);
+ * only when a block then does not inflate is the output laid out and written a second time, with
+ * that batch passed through.
  * totals (not NULL: the call waits) has out_bytes, the bytes of the frame, and n_failed, the
  * number of batches that did not inflate. */
 int nisshi_hip_inflate_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
