@@ -134,3 +134,22 @@ def test_workload_of_many_batches(codec):
         if name not in ("crc",):
             n = totals.n_headers if name in header_level else len(g[name])
             assert (g[name][:n] == w[name][:n]).all(), name
+
+
+def test_a_frame_of_thousands_of_small_batches(codec):
+    """More batches than one pass of the layout's scan takes (1024), all four kinds and plain ones mixed, a
+    damaged one every so often: offsets, statuses and bytes against the restatement."""
+    rng = np.random.default_rng(99)
+    batches = []
+    for i in range(3000):
+        value = bytes(rng.integers(97, 100, int(rng.integers(1, 120)), dtype=np.uint8))
+        plain = build_batch(dict(base_offset=i), [C.Record(0, 0, 0, 0, b"k%d" % i, value)])
+        kind = i % 5
+        b = [plain, gzip_batch(plain), snappy_batch(plain), lz4_batch(plain), gzip_batch(plain, level=0)][kind]
+        if i % 97 == 0 and kind:
+            b = bytearray(b)
+            b[-3] ^= 0x5A
+            b = bytes(b)
+        batches.append(b)
+    got, got_off, status = check(codec, batches)
+    assert {int(s) for s in status} == {C.OK, hip.NONE, hip.INFLATE}
