@@ -521,7 +521,7 @@ int nisshi_hip_pool_create_custom(uint32_t n_devices, nisshi_pool_decode_fn deco
  * d_out_off receives n_batches + 1 offsets into d_out.  With d_out == NULL the call only says how
  * much room the output needs: totals->out_bytes is a capacity that holds it whatever the blocks
  * turn out to be (each batch counted at the larger of its own size and what its Snappy block or
- * gzip member announces, an LZ4 batch with its frame's blocks at their maximal size; a block that announces more than 22 bytes
+ * gzip member announces, an LZ4 batch with what its frame's blocks can hold at most; a block that announces more than 22 bytes
  * a byte of its own cannot inflate and is not counted so); d_status and d_out_off are not final then.  Otherwise a d_out of out_cap bytes (16-byte
  * aligned) receives the frame; NISSHI_CAPACITY when out_cap is below that capacity.  The output
  * is laid out by what the blocks announce and written by one walk over them (LZ4 frames, which

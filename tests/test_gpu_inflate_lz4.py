@@ -127,6 +127,28 @@ def test_workload_of_many_batches(codec):
             assert (g[name][:n] == w[name][:n]).all(), name
 
 
+def test_small_batches_of_large_blocks_ask_for_little_room(codec):
+    """Frames that announce 4 MiB blocks and hold a few hundred bytes: the room the call asks for follows the bytes
+    (255 a byte of a block at most), not the announced block size."""
+    plains = [build_batch(dict(base_offset=i), [C.Record(0, 0, 0, 0, b"k%d" % i, b"value " * (i % 50 + 1))]) for i in range(300)]
+    batches = [lz4_batch(p, size_id=7, linked=bool(i & 1)) for i, p in enumerate(plains)]
+    blob = b"".join(batches)
+    totals = hip.Totals()
+    arr = np.frombuffer(blob, dtype=np.uint8)
+    off = offsets_of(batches)
+    out_off, status = np.zeros(len(batches) + 1, dtype=np.uint64), np.zeros(len(batches), dtype=np.int32)
+    import ctypes
+    st = codec.lib.nisshi_hip_inflate(codec.ctx, arr.ctypes.data, len(arr), off.ctypes.data, len(batches), None, 0,
+                                      out_off.ctypes.data, status.ctypes.data, ctypes.byref(totals))
+    assert st == C.CAPACITY
+    assert len(b"".join(plains)) <= totals.out_bytes <= 255 * len(blob)
+    got, got_off, status = check(codec, batches)
+    assert all(int(s) == C.OK for s in status)
+    for i, plain in enumerate(plains):
+        a = got[int(got_off[i]):int(got_off[i + 1])]
+        assert a[:17] == plain[:17] and a[21:] == plain[21:]
+
+
 def test_damaged_streams_of_both_codecs(codec):
     """A thousand Snappy blocks and LZ4 frames with a few bytes changed, cut short or lengthened: whatever the
     restatement makes of each (most do not inflate, some inflate to other bytes), the device makes the same."""
