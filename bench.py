@@ -2,6 +2,13 @@
 """Device-resident RecordBatch v2 decode throughput on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--workload c2]
+    python bench.py --pool G            # one host frame over G devices (PCIe inclusive)
+
+With --gpus N > 1 and no WORLD_SIZE in the environment, this process touches no
+GPU: it starts N fresh processes of itself, one a rank (RANK, LOCAL_RANK,
+WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT), passes rank 0's line on and
+exits non-zero if any rank did.  Under `python -m torch.distributed.run` the ranks
+are already there and each runs its share directly.
 
 One step = one decode of the whole resident workload (batch headers, CRC-32C,
 record walk into columns, header spans) through the C ABI.  At N > 1 every rank
@@ -70,14 +77,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-copies", action="store_true",
                     help="also time the host-buffer entry point (PCIe inclusive), to stderr")
+    ap.add_argument("--pool", type=int, default=0, metavar="G",
+                    help="instead of the device-resident decode: one host frame of the mixed workload over G "
+                         "devices through nisshi_hip_pool_decode, copies included (G of 1, 2, 4, 8)")
     args = ap.parse_args()
 
+    from tansu_amd import shard
+    if args.pool:
+        return pool_bench(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no rank exists yet: start them, before anything here touches a GPU
+        sys.exit(shard.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
     import torch
-    from tansu_amd import columns as C, hip, shard
+    from tansu_amd import columns as C, hip
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the job has {world} ranks", file=sys.stderr)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -144,8 +163,9 @@ def main():
         codec.profile(True, only=state["dominant"], every=EVENTS_EVERY)
 
     codec.profile(True)
+    per_rank = []
     elapsed = shard.run_timed(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev),
-                              dist if world > 1 else None, dev, on_start=on_start)
+                              dist if world > 1 else None, dev, on_start=on_start, per_rank=per_rank)
     kt = codec.kernel_times()
     codec.profile(False)
     kt_all = state["all"] or kt
@@ -192,6 +212,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": step_ms,
+        "ms_per_step_ranks": [t / args.steps * 1e3 for t in per_rank],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -301,15 +322,98 @@ def main():
         result["cpu_baseline"] = cpu_baseline(blob, off, n_batches, n_records)
         if args.workload != "c1":
             # C1 is the configuration the reference's own benchmark runs on a CPU: the same two
-            # decodes on a sample of it, one core, beside this workload's
+            # decodes over all of it (10 000 batches, 110 MB: beyond the caches), one core,
+            # beside this workload's
             from tansu_amd import synth
-            c1_blob, c1_off, c1_nr, _ = synth.make_batches(*synth.config("c1", 0.05))
+            c1_blob, c1_off, c1_nr, _ = synth.make_batches(*synth.config("c1", 1.0))
             result["cpu_baseline_c1"] = cpu_baseline(c1_blob, c1_off, len(c1_off) - 1, c1_nr, budget_s=4.0,
                                                      all_cores=False)
 
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pool_bench(args):
+    """One host frame of the mixed workload (C4's partitions of the first G devices
+    of a node, in partition order) through nisshi_hip_pool_decode: the pool gathers
+    each device's batches into page-locked staging, every device copies in, decodes
+    and copies its columns out, side by side, and the pool puts the columns back in
+    input order.  Everything is timed from host memory to host memory; on a box
+    with fewer than G GPUs the device ids repeat (several contexts a GPU), which
+    rehearses the scheduling but shares one GPU's PCIe link."""
+    import torch
+    from tansu_amd import columns as C, hip, shard
+    g = args.pool
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise RuntimeError("no GPU visible: the HIP codec has no CPU fallback")
+    blob, off, partition, n_records, n_headers = shard.pool_frame(args.scale, g)
+    n_batches = len(off) - 1
+    ids = [d % n_dev for d in range(g)]
+    pool = hip.Pool(ids)
+    # fill the CRC fields (a one-GPU decode of the same frame), so that the pool decodes valid batches
+    codec = hip.Codec(0)
+    d_blob, d_off = codec.to_device(blob, off)
+    cols = hip.DeviceColumns(n_batches, n_records, max(n_headers, 1), codec.device)
+    codec.decode_dev(d_blob, len(blob), d_off, n_batches, cols)
+    from tansu_amd import synth
+    synth.patch_crc(blob, off, cols.t["crc_computed"][:n_batches].cpu().numpy().view(np.uint32))
+    d_blob, d_off = codec.to_device(blob, off)
+    codec.decode_dev(d_blob, len(blob), d_off, n_batches, cols)
+    want = cols.to_host(n_records, n_headers)
+    del cols, d_blob, d_off
+    hdr_cap = max(n_headers, 1) + 16 * g
+    arrays = C.alloc_device_layout(n_batches, n_records, hdr_cap)
+    blob = np.ascontiguousarray(blob)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    for _ in range(max(args.warmup, 1)):
+        totals, per_device = pool.decode_into(blob, off, partition, arrays, n_records, hdr_cap)
+    assert (totals.n_records, totals.n_headers, totals.n_failed) == (n_records, n_headers, 0), \
+        (totals.n_records, totals.n_headers, totals.n_failed)
+    # the pool's columns against one device's decode of the whole frame: batch for batch the same
+    # records (a device's records are one run, so slots differ: compare through rec_base)
+    got = C.unpack(arrays)
+    order_g = np.argsort(got["rec_base"][:n_batches], kind="stable")
+    order_w = np.argsort(want["rec_base"][:n_batches], kind="stable")
+    for f in ("record_count", "crc", "crc_computed", "status", "batch_length", "base_offset"):
+        assert (got[f][:n_batches] == want[f][:n_batches]).all(), f
+    cnt = want["record_count"][:n_batches].astype(np.int64)
+    idx_g = np.repeat(got["rec_base"][:n_batches].astype(np.int64), cnt) + \
+        (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    idx_w = np.repeat(want["rec_base"][:n_batches].astype(np.int64), cnt) + \
+        (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    for f in ("length", "offset_delta", "key_off", "key_len", "val_off", "val_len", "hdr_count", "timestamp_delta"):
+        assert (got[f][idx_g] == want[f][idx_w]).all(), f
+    del order_g, order_w
+    steps = max(1, min(args.steps, 10))
+    times = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pool.decode_into(blob, off, partition, arrays, n_records, hdr_cap)
+        times.append(pool.last_times())
+    elapsed = time.perf_counter() - t0
+    pool.close()
+    codec.close()
+    mean = {k: sum(t[k] for t in times) / len(times) for k in times[0]}
+    algo = C.algorithmic_decode_bytes(n_batches, n_records, n_headers, len(blob))
+    print(json.dumps({
+        "metric": "one host frame over G devices, host memory to host memory (nisshi_hip_pool_decode)",
+        "value": n_records * steps / elapsed, "unit": "records/s", "n_gpus": len(set(ids)), "pool_devices": g,
+        "device_ids": ids, "steps": steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"C4 as one host frame: {n_batches} batches of {len(set(partition.tolist()))} "
+                               f"partitions (five shapes by p mod 5, 64 batches each), device = partition mod {g}",
+                   "input_bytes": int(len(blob)), "records": n_records, "headers": n_headers},
+        "input_gbs": len(blob) * steps / elapsed / 1e9,
+        "moved_gbs": algo * steps / elapsed / 1e9,
+        "pool_ms": mean,
+        "pool_ms_what": "host clock, the slowest device's: gather = its batches into page-locked staging; decode = "
+                        "nisshi_hip_decode (copy in, kernels, copy out); scatter = its columns into the caller's, "
+                        "header slots rebased; call = the whole nisshi_hip_pool_decode",
+        "per_device_records": [int(t.n_records) for t in per_device],
+        "checked": "columns equal one device's decode of the whole frame, batch for batch",
+    }))
 
 
 def device_copy_gbs(dev, n_bytes=1 << 30, reps=10):

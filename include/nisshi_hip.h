@@ -470,6 +470,12 @@ void nisshi_hip_pool_destroy(nisshi_hip_pool *pool);
 uint32_t nisshi_hip_pool_device_count(const nisshi_hip_pool *pool);
 uint32_t nisshi_hip_pool_device_of(const nisshi_hip_pool *pool, uint32_t partition);
 const char *nisshi_hip_pool_last_error(const nisshi_hip_pool *pool);
+/* Where the last nisshi_hip_pool_decode spent its time, in milliseconds of host
+ * clock: ms[0] gathering a device's batches into its staging blob, ms[1] in that
+ * device's decode (copy in, kernels, copy out), ms[2] putting its columns back
+ * into the caller's -- each the slowest device's, the devices work side by side --
+ * and ms[3] the whole call.  (Measurement only: no counterpart in the reference.) */
+void nisshi_hip_pool_last_times(const nisshi_hip_pool *pool, double *ms);
 /* partition: one id a batch.  totals: those of the frame; device_totals (or NULL):
  * n_devices entries, each device's own.  Capacities are those of the caller's
  * columns (header slots with the slack nisshi_hip_decode_dev describes, summed

@@ -176,6 +176,7 @@ extern "C" {
     pub fn nisshi_hip_pool_device_count(pool: *const Pool) -> u32;
     pub fn nisshi_hip_pool_device_of(pool: *const Pool, partition: u32) -> u32;
     pub fn nisshi_hip_pool_last_error(pool: *const Pool) -> *const c_char;
+    pub fn nisshi_hip_pool_last_times(pool: *const Pool, ms: *mut f64);
     pub fn nisshi_hip_pool_decode(pool: *mut Pool, blob: *const u8, blob_len: u64, batch_off: *const u64, n_batches: u32, partition: *const u32, by_value: c_int, cols: *const Columns, rec_cap: u64, hdr_cap: u64, totals: *mut Totals, device_totals: *mut Totals) -> c_int;
     pub fn nisshi_hip_pool_create_custom(n_devices: u32, decode: PoolDecodeFn, decoder_ctx: *const *mut c_void, pool: *mut *mut Pool) -> c_int;
     pub fn nisshi_hip_inflate_dev(ctx: *mut Ctx, d_blob: *const u8, blob_len: u64, d_batch_off: *const u64, n_batches: u32, d_out: *mut u8, out_cap: u64, d_out_off: *mut u64, d_status: *mut i32, totals: *mut Totals, stream: *mut c_void) -> c_int;

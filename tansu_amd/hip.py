@@ -29,7 +29,7 @@ EXPORTS = [
     "nisshi_hip_compact_dev", "nisshi_hip_compact", "nisshi_hip_inflate_dev", "nisshi_hip_inflate",
     "nisshi_hip_pool_create", "nisshi_hip_pool_create_custom", "nisshi_hip_pool_destroy",
     "nisshi_hip_pool_device_count", "nisshi_hip_pool_device_of", "nisshi_hip_pool_last_error",
-    "nisshi_hip_pool_decode",
+    "nisshi_hip_pool_last_times", "nisshi_hip_pool_decode",
 ]
 
 POOL_DECODE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
@@ -166,6 +166,8 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_pool_device_of.restype = u32
     lib.nisshi_hip_pool_last_error.argtypes = [vp]
     lib.nisshi_hip_pool_last_error.restype = ctypes.c_char_p
+    lib.nisshi_hip_pool_last_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+    lib.nisshi_hip_pool_last_times.restype = None
     lib.nisshi_hip_pool_decode.argtypes = [vp, vp, u64, vp, u32, vp, i32, ctypes.POINTER(C.CColumns), u64, u64,
                                            ctypes.POINTER(Totals), vp]
     lib.nisshi_hip_profile_enable.argtypes = [vp, i32]
@@ -730,6 +732,27 @@ class Pool:
 
     def device_of(self, partition: int) -> int:
         return self.lib.nisshi_hip_pool_device_of(self.pool, partition)
+
+    def last_times(self) -> dict:
+        """Host-clock milliseconds of the last decode: the slowest device's gather,
+        decode (copies and kernels) and scatter, and the whole call."""
+        ms = (ctypes.c_double * 4)()
+        self.lib.nisshi_hip_pool_last_times(self.pool, ms)
+        return {"gather_ms": ms[0], "decode_ms": ms[1], "scatter_ms": ms[2], "call_ms": ms[3]}
+
+    def decode_into(self, arr: np.ndarray, off: np.ndarray, part: np.ndarray, arrays: dict, rec_cap: int,
+                    hdr_cap: int, by_value: bool = True):
+        """Decode into caller-held arrays in the device layout: (totals, per-device totals)."""
+        cc = C.as_c(arrays)
+        totals = Totals()
+        per_device = (Totals * self.n)()
+        n_b = len(off) - 1
+        st = self.lib.nisshi_hip_pool_decode(self.pool, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data,
+                                             n_b, part.ctypes.data if n_b else None, int(by_value), ctypes.byref(cc),
+                                             rec_cap, hdr_cap, ctypes.byref(totals), per_device)
+        if st:
+            raise NisshiError(st, (self.lib.nisshi_hip_pool_last_error(self.pool) or b"").decode())
+        return totals, list(per_device)
 
     def decode(self, blob, batch_off, partition, rec_cap: int, hdr_cap: int, by_value: bool = True):
         """Returns (cols: dict of numpy arrays in the device layout's fields, totals, per-device totals)."""
