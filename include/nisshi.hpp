@@ -75,6 +75,9 @@ struct Error {
         Device,
         InvalidArgument,
         Inflate,                 // gzip, Snappy or LZ4 record data that does not inflate (the inflator's Error::Snap / Error::Io)
+        InflatedRecords,         // record data that inflated but whose records do not decode: the reference reads
+                                 // them through serde over the inflator's reader (deflated.rs:444-457) and returns
+                                 // Err (Error::Io or Error::Message) -- it never panics there; detail = the decode's status
     } kind;
     int detail;
     std::string message;
@@ -518,7 +521,12 @@ inline Result<inflated::Frame> inflate(Codec &codec, const deflated::Frame &fram
     for (size_t b = 0; b < nb; b++) {
         const deflated::Batch &d = frame.batches[b];
         // the first failing batch is the frame's error (collect::<Result<Vec<_>>>)
+        // (this mirror has no CPU path of its own: where the Rust patch hands such a batch to the existing
+        // code, which also accepts a member or frame damaged only behind its last record, the mirror reports)
         if (inflated_status[b] == NISSHI_INFLATE) return Error::from_status(NISSHI_INFLATE, d.attributes & 7);
+        if (cols.status[b] && inflated_status[b] == NISSHI_OK)
+            return Error{Error::InflatedRecords, cols.status[b],
+                         std::string("records of an inflated batch do not decode: ") + nisshi_hip_status_str(cols.status[b])};
         if (cols.status[b]) return Error::from_status(cols.status[b], d.attributes & 7);
         // an inflated batch: its records lie in the rewritten frame; batch_length and, by reference,
         // attributes are the compressed batch's (inflated.rs:114-187 copies them from the deflated batch)

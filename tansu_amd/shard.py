@@ -96,12 +96,15 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(cmd: Sequence[str], world: int, timeout: Optional[float] = None, out=None, err=None) -> int:
+def launch_ranks(cmd: Sequence[str], world: int, timeout: Optional[float] = None, out=None, err=None,
+                 result_line: Optional[Callable[[str], bool]] = None) -> int:
     """Run `cmd` as `world` fresh processes, one a rank, each with the environment
     of `rank_env`, and wait for them.  The caller must not have touched the GPU:
     every rank is a child of its own, started before any device call is made here.
     Rank 0's standard output is passed on (`out`, default this process's), the
-    other ranks' goes to `err` so that the job prints ONE result line.  Returns 0
+    other ranks' goes to `err` so that the job prints ONE result line (with
+    `result_line`, only rank 0's lines for which it holds are passed on to `out`:
+    libraries print notices of their own to standard output).  Returns 0
     when every rank did; otherwise the first non-zero exit code seen, after the
     ranks still running were ended (by their own process ids); 124 on `timeout`."""
     out = sys.stdout if out is None else out
@@ -141,8 +144,9 @@ def launch_ranks(cmd: Sequence[str], world: int, timeout: Optional[float] = None
         f.seek(0)
         text = f.read()
         f.close()
-        if text:
-            (out if r == 0 else err).write(text)
+        for line in text.splitlines(keepends=True):
+            mine = r == 0 and (result_line is None or result_line(line))
+            (out if mine else err).write(line)
     out.flush()
     return code
 

@@ -146,6 +146,22 @@ static void inflate_compressed_batches(Codec &codec) {
     auto zs = deflated::Batch::try_from(Bytes(kZstdBatch, sizeof(kZstdBatch))).unwrap();
     auto bad = inflated::Batch::try_from(codec, zs);
     CHECK(bad.is_err() && bad.error().kind == Error::Compressed && bad.error().detail == 4);
+    // A Snappy block that inflates, to six bytes that are no record (a key of length -3).  The reference
+    // reads an inflated batch's records through serde over the inflator's reader (deflated.rs:444-457)
+    // and returns Err there, where Record::decode on an uncompressed batch would panic: the mirror
+    // reports it as an error of its own kind, never as Malformed.
+    const uint8_t block[] = {6, 5 << 2, 0x0A, 0x00, 0x00, 0x00, 0x05, 0x00};
+    deflated::Batch odd = deflated::Batch::try_from(Bytes(kBatch71, sizeof(kBatch71))).unwrap();
+    odd.attributes = 2;
+    odd.record_data = Bytes(block, sizeof(block));
+    odd.batch_length = int32_t(49 + sizeof(block));
+    bad = inflated::Batch::try_from(codec, odd);
+    CHECK(bad.is_err() && bad.error().kind == Error::InflatedRecords && bad.error().detail == NISSHI_MALFORMED);
+    odd.attributes = 0;  // the same six bytes as an uncompressed batch's record data: the reference panics
+    odd.record_data = Bytes(block + 2, 6);
+    odd.batch_length = 49 + 6;
+    bad = inflated::Batch::try_from(codec, odd);
+    CHECK(bad.is_err() && bad.error().kind == Error::Malformed);
 }
 
 static void records_with_keys_and_headers_round_trip(Codec &codec) {
