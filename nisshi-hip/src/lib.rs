@@ -261,31 +261,65 @@ impl Codec {
         by_value: bool,
         record_counts: Option<u64>,
     ) -> Result<(HostColumns, Totals)> {
-        let n = batch_off.len().saturating_sub(1);
+        let n = Self::checked_batches(blob, batch_off, "nisshi_hip_decode")?;
         // a record is at least seven bytes, a header at least two (header.rs:31-41)
         let most = blob.len() as u64 / 7 + 1;
         let rec_cap = record_counts.map_or(most, |c| c.min(most));
-        let hdr_cap = blob.len() as u64 + 1; // covers every call: see nisshi_hip_decode_dev in nisshi_hip.h
-        let mut cols = HostColumns::with_capacity(n, rec_cap as usize, hdr_cap as usize);
-        let mut totals = Totals::default();
-        let c = cols.as_ffi();
-        let st = unsafe {
-            ffi::nisshi_hip_decode(
-                self.ctx,
-                blob.as_ptr(),
-                blob.len() as u64,
-                batch_off.as_ptr(),
-                n as u32,
-                by_value as c_int,
-                &c,
-                rec_cap,
-                hdr_cap,
-                &mut totals,
-            )
-        };
-        if st != ffi::NISSHI_OK {
-            return Err(self.fail(st, "nisshi_hip_decode"));
+        // blob.len() + 1 header slots cover every call (see nisshi_hip_decode_dev in nisshi_hip.h), but
+        // zeroing sixteen bytes a blob byte would cost more than the decode: start at an eighth and grow
+        // while a batch reports that its headers had no room
+        let hdr_most = blob.len() as u64 + 1;
+        let mut hdr_cap = hdr_most.min((blob.len() as u64 / 8).max(1024));
+        loop {
+            let mut cols = HostColumns::with_capacity(n, rec_cap as usize, hdr_cap as usize);
+            let mut totals = Totals::default();
+            let c = cols.as_ffi();
+            let st = unsafe {
+                ffi::nisshi_hip_decode(
+                    self.ctx,
+                    blob.as_ptr(),
+                    blob.len() as u64,
+                    batch_off.as_ptr(),
+                    n as u32,
+                    by_value as c_int,
+                    &c,
+                    rec_cap,
+                    hdr_cap,
+                    &mut totals,
+                )
+            };
+            if st != ffi::NISSHI_OK {
+                return Err(self.fail(st, "nisshi_hip_decode"));
+            }
+            let short = hdr_cap < hdr_most
+                && totals.n_failed > 0
+                && (0..n).any(|b| cols.status_of(b) == Status::Capacity);
+            if !short {
+                return Ok((cols, totals));
+            }
+            hdr_cap = hdr_most.min((2 * hdr_cap).max(totals.n_headers));
         }
+    }
+
+    /// What the safe entry points check before the `unsafe` call: `batch_off` holds
+    /// the start of every batch and the end of the last (so at least one entry), in
+    /// ascending order, none past the end of `blob`.  The library checks the same
+    /// (`NISSHI_INVALID_ARGUMENT`); the kernels read `blob + batch_off[b]` unchecked.
+    fn checked_batches(blob: &[u8], batch_off: &[u64], what: &str) -> Result<usize> {
+        let ok = !batch_off.is_empty()
+            && batch_off.len() - 1 <= u32::MAX as usize
+            && batch_off.windows(2).all(|w| w[0] <= w[1])
+            && batch_off[batch_off.len() - 1] <= blob.len() as u64;
+        if ok {
+            Ok(batch_off.len() - 1)
+        } else {
+            Err(Error {
+                status: Status::InvalidArgument,
+                detail: format!("{what}: batch_off must hold n + 1 ascending offsets within the blob"),
+            })
+        }
+    }
+
         Ok((cols, totals))
     }
 
@@ -335,7 +369,7 @@ impl Codec {
     /// frame's bytes, the start of each batch (`n + 1` offsets) and a status a batch: `Ok` inflated,
     /// `Inflate` the record data does not inflate (passed through), `None` passed through.
     pub fn inflate(&mut self, blob: &[u8], batch_off: &[u64]) -> Result<(Vec<u8>, Vec<u64>, Vec<Status>, Totals)> {
-        let n = batch_off.len().saturating_sub(1);
+        let n = Self::checked_batches(blob, batch_off, "nisshi_hip_inflate")?;
         let mut out_off = vec![0u64; n + 1];
         let mut status = vec![0i32; n.max(1)];
         let mut totals = Totals::default();

@@ -1,12 +1,14 @@
 """nisshi_hip_decode_dev_static (the decode entry point that allocates nothing)
-against nisshi_hip_decode_dev, through the C ABI: the same batches must give the
-same columns, bit for bit, on two calls in a row, the second with a smaller
-input (the static workspace keeps what the first call left in it)."""
+against nisshi_hip_decode_dev and against the CPU checker (oracle/), through the
+C ABI: the same batches must give the same columns, bit for bit, on two calls in
+a row, the second with a smaller input (the static workspace keeps what the
+first call left in it)."""
 import ctypes
 
 import numpy as np
 import pytest
 
+import oracle
 from tansu_amd import columns as C, hip, synth
 from util import assert_same
 
@@ -53,6 +55,11 @@ def both(codec, blob, off):
     assert int(a["hdr_count"][:n_b].sum()) == int(b["hdr_count"][:n_b].sum())
     assert ta.n_failed == 0 and (a["crc_computed"][:n_b] == b["crc_computed"][:n_b]).all()
     assert_same(b, a, n_b)   # every batch and record field, headers through each record's slots
+    # and both against the CPU restatement of the reference's decode
+    st, want, nr, nh = oracle.decode_columns(blob, off)
+    assert st == C.OK and (tb.n_records, int(b["hdr_count"][:n_b].sum())) == (nr, nh)
+    assert_same(b, want, n_b)
+    assert_same(a, want, n_b)
     return ta
 
 
