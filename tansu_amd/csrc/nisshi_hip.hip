@@ -763,9 +763,18 @@ constexpr int kWalkFull = 4;    // the walk of a piece of a batch only: the head
 // of attributes, timestamp_delta and offset_delta: the bytes of every length and
 // count varint and the widths of the two deltas.  Records produced by one client
 // mostly share a shape, and a record of a known shape needs no varint walk: its
-// fields sit at known offsets.  The wave learns the shape of a record as a list
-// of masked 32-bit compares (kept in LDS, as are the header spans relative to the
-// record start) and tests the records that follow against it, 64 at a time.
+// fields sit at known offsets.  The wave learns the shape of a record and tests the
+// records that follow against it, 64 at a time.
+//
+// A shape has two parts.  The head -- the length varint, the attributes byte and
+// the two deltas -- is held as a few scalars (the bytes of the length, the widths
+// of the deltas) and tested by arithmetic on what a lane reads there anyway.  The
+// rest, from the key's length on, is a list of masked 32-bit compares (kept in LDS,
+// as are the header spans) whose offsets count from the end of the offset delta.
+// So when the deltas of a batch's records grow a byte (record 64, record 8192 of
+// every batch a producer numbers 0, 1, 2, ...) and the length with them, the shape
+// is re-based from the first such record by changing the scalars alone
+// (walk_streamed), and nothing is learnt again.
 constexpr uint32_t kShapeChecks = 24;  // a multiple of four
 constexpr uint32_t kShapeHdrs = 16;
 constexpr uint32_t kShapeWords = (kShapeChecks + kShapeHdrs + 3) * 4;  // and the learnt scalars
@@ -775,10 +784,14 @@ struct Shape {
     uint32_t size;      // bytes of a record of this shape, its length varint included
     uint32_t n_len;     // bytes of the length varint
     int32_t length;     // its value
-    uint32_t o_od;      // offsets from the start of the record
-    uint32_t o_key, o_val;
+    uint32_t lenpat;    // its bytes (little-endian, the n_len low bytes)
+    uint32_t wts, wod;  // bytes of the timestamp delta and of the offset delta
+    uint32_t o_fix;     // n_len + 1 + wts + wod: where the key's length starts; the table's offsets count from here
+    uint32_t o_key, o_val;  // offsets from the start of the record
     int32_t klen, vlen;
     uint32_t hc;
+
+    __device__ __forceinline__ uint32_t lenmask() const { return n_len >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * n_len)); }
 };
 
 // Reads of the wave's LDS ring at any byte position.  `at` is a position in the
@@ -835,8 +848,10 @@ struct RingView {
 //
 // The fields are walked by one loop: 0 length, 1 timestamp delta (after the
 // attributes byte), 2 offset delta, 3 key, 4 value, 5 header count, then a key
-// and a value per header.  The bytes of every varint belong to the shape, except
-// that of the two deltas only the widths do.
+// and a value per header.  Of the first three the scalars of the head are noted;
+// the bytes of every varint from the key's length on go into the compares, at
+// offsets from where that length starts, and the spans of key, value and headers
+// are noted from there too.
 //
 // Tab: where the table goes (LDS, or global memory for a guess handed to other
 // waves); Src: where the record's bytes come from, read64(position).  kGuard: the
@@ -848,11 +863,10 @@ __device__ __forceinline__ int learn_shape_any(Tab tab, Src &ring, uint32_t at0,
     uint32_t p = 0;  // offset in the record
     uint32_t cur_off = 0, cur_mask = 0, cur_pat = 0, noted = 0;
     uint32_t fields = 6;
-    uint32_t n_len = 0, o_od = 0, o_key = 0, o_val = 0, hc = 0, ko = 0;
+    uint32_t n_len = 0, wts = 0, wod = 0, o_fix = 0, lenpat = 0, o_key = 0, o_val = 0, hc = 0, ko = 0;
     int32_t length = 0, klen = 0, vlen = 0, kl = 0;
     bool wide = false, bad = false;
     for (uint32_t i = 0; i < fields && !bad; i++) {
-        bool delta = i == 1 || i == 2;
         if (i == 1) p += 1;
         if (kGuard && p >= size) {
             bad = true;
@@ -863,33 +877,43 @@ __device__ __forceinline__ int learn_shape_any(Tab tab, Src &ring, uint32_t at0,
         int32_t v;
         bad = !fast_varint(w, used, v);
         wide = wide || used > 4;
-        // into the compare in hand if it fits, else start the next
         uint32_t bytes = used >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * used));
-        uint32_t mk = delta ? bytes & 0x80808080u : bytes;
-        if (p + used > cur_off + 4) {
+        if (i < 3) {  // the head: scalars
+            if (i == 0) {
+                n_len = used;
+                length = v;
+                lenpat = (uint32_t)w & bytes;
+            } else if (i == 1) {
+                wts = used;
+            } else {
+                wod = used;
+            }
+            p += used;
+            o_fix = p;
+            continue;
+        }
+        uint32_t q = p - o_fix;  // the varint's offset from the end of the head
+        // into the compare in hand if it fits, else start the next
+        if (q + used > cur_off + 4) {
             if (noted < kShapeChecks) tab[noted] = u32x4{cur_off, cur_mask, cur_pat, 0};
             noted++;
-            cur_off = p;
+            cur_off = q;
             cur_mask = 0;
             cur_pat = 0;
         }
-        uint32_t sh = (p - cur_off) * 8;
-        cur_mask |= mk << sh;
-        cur_pat |= ((uint32_t)w & mk) << sh;
-        if (i == 2) o_od = p;
+        uint32_t sh = (q - cur_off) * 8;
+        cur_mask |= bytes << sh;
+        cur_pat |= ((uint32_t)w & bytes) << sh;
         p += used;
-        if (i == 0) {
-            n_len = used;
-            length = v;
-        } else if (i == 5) {
+        if (i == 5) {
             // a header is at least two bytes: a count the record cannot hold is an error
             bad = bad || v < 0 || p > size || (uint32_t)v > (size - p) / 2;
             hc = bad ? 0 : (uint32_t)v;
             fields = 6 + 2 * (hc <= kShapeHdrs ? hc : 0);
-        } else if (!delta) {
+        } else {
             // Octets::decode: -1 is None, any other negative length or one past the record is an error
             bad = bad || v < -1 || p > size || (uint32_t)(v < 0 ? 0 : v) > size - p;
-            uint32_t off = p;
+            uint32_t off = p - o_fix;
             p += !bad && v > 0 ? (uint32_t)v : 0u;
             if (i == 3) {
                 klen = v;
@@ -914,7 +938,7 @@ __device__ __forceinline__ int learn_shape_any(Tab tab, Src &ring, uint32_t at0,
     if (wide || hc > kShapeHdrs || noted > kShapeChecks) st = kWalkChain;
     // the fields must end exactly where the length said
     else if (bad || p != size) st = kWalkExact;
-    out[0] = u32x4{(noted + 3) & ~3u, n_len, (uint32_t)length, o_od};
+    out[0] = u32x4{(noted + 3) & ~3u, n_len | (wts << 8) | (wod << 16), (uint32_t)length, lenpat};
     out[1] = u32x4{o_key, o_val, (uint32_t)klen, (uint32_t)vlen};
     out[2] = u32x4{hc, (uint32_t)st, size, 0};
     return st;
@@ -990,22 +1014,30 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     shape.n_checks = 0;
     shape.size = 0;
     shape.hc = 0;
-    if (guessed) {
-        // `tab` holds a shape already (guess_shape's, of a batch nearby): the walk starts
-        // with it in hand as if it had learnt it from a record before
+    // the shape whose table lies in `tab` (learn_shape_any has just left it there, or it is a guess)
+    auto load_shape = [&]() -> int {
         const lds_u128 *in4 = htab + kShapeHdrs;
         u32x4 a = in4[0], b4 = in4[1], c4 = in4[2];
-        shape.n_checks = uni(a.x);
+        int learnt = (int)uni(c4.y);
+        shape.n_checks = learnt == kWalkDone ? uni(a.x) : 0;
         shape.size = uni(c4.z);
-        shape.n_len = uni(a.y);
+        uint32_t widths = uni(a.y);
+        shape.n_len = widths & 0xffu;
+        shape.wts = (widths >> 8) & 0xffu;
+        shape.wod = (widths >> 16) & 0xffu;
+        shape.o_fix = shape.n_len + 1 + shape.wts + shape.wod;
         shape.length = (int32_t)uni(a.z);
-        shape.o_od = uni(a.w);
-        shape.o_key = uni(b4.x);
-        shape.o_val = uni(b4.y);
+        shape.lenpat = uni(a.w);
+        shape.o_key = shape.o_fix + uni(b4.x);
+        shape.o_val = shape.o_fix + uni(b4.y);
         shape.klen = (int32_t)uni(b4.z);
         shape.vlen = (int32_t)uni(b4.w);
         shape.hc = uni(c4.x);
-    }
+        return learnt;
+    };
+    // `tab` holds a shape already (guess_shape's, of a batch nearby): the walk starts
+    // with it in hand as if it had learnt it from a record before
+    if (guessed) load_shape();
     // The stores of a round are issued in the next round, after that round's rows
     // have been taken from the look-ahead queue and before the queue is refilled:
     // the wait for the queued loads then never waits for stores just issued, and
@@ -1042,20 +1074,40 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         for (uint32_t j = 0; j < shape.hc; j++, o += 16) {
             u32x4 e = htab[j];
             if (live)
-                put(reinterpret_cast<u32x4 *>(c.hdr + late.piece), o, u32x4{late.start + e.x, e.y, late.start + e.z, e.w});
+                put(reinterpret_cast<u32x4 *>(c.hdr + late.piece), o,
+                    u32x4{late.start + shape.o_fix + e.x, e.y, late.start + shape.o_fix + e.z, e.w});
         }
     };
-    // how many of the first m lanes' records, counted from lane 0, have the shape in hand
+    // How many of the first m lanes' records, counted from lane 0, have the shape in
+    // hand.  The head by arithmetic: the bytes of the length, and the widths of the
+    // two deltas, whose values (and the attributes byte) the lane keeps for the
+    // records that fit; the rest by the table's compares.
+    // (they go straight into `late`: the round before was flushed before any test of this one)
     auto fitting = [&](uint32_t at, uint32_t m) -> uint32_t {
         if (shape.n_checks == 0) return 0;
         uint32_t diff = 0;
+        uint32_t at2 = at + shape.o_fix;
         // four compares at a time so that the ring reads overlap (the table is
         // padded with compares that always hold)
         for (uint32_t s = 0; s < shape.n_checks; s += 4) {
             u32x4 e0 = tab[s], e1 = tab[s + 1], e2 = tab[s + 2], e3 = tab[s + 3];
-            uint32_t w0 = ring.read32(at + e0.x), w1 = ring.read32(at + e1.x);
-            uint32_t w2 = ring.read32(at + e2.x), w3 = ring.read32(at + e3.x);
+            uint32_t w0 = ring.read32(at2 + e0.x), w1 = ring.read32(at2 + e1.x);
+            uint32_t w2 = ring.read32(at2 + e2.x), w3 = ring.read32(at2 + e3.x);
             diff |= ((w0 ^ e0.z) & e0.y) | ((w1 ^ e1.z) & e1.y) | ((w2 ^ e2.z) & e2.y) | ((w3 ^ e3.z) & e3.y);
+        }
+        // (the head last: the values it leaves in `late` are then not held across the compares)
+        diff |= (ring.read32(at) ^ shape.lenpat) & shape.lenmask();
+        {
+            uint32_t w_used;
+            int64_t ts;
+            uint64_t r1 = ring.read40(RingCfg<kRows>::wrap(at + shape.n_len));  // attributes, then the timestamp delta
+            late.attributes = (uint32_t)r1 & 0xffu;
+            bool ok = fast_varlong((uint32_t)(r1 >> 8), w_used, ts);  // a shape's timestamp delta has at most four bytes
+            late.ts = (int32_t)ts;
+            diff |= (w_used ^ shape.wts) | (ok ? 0u : 1u);
+            uint32_t o_used;
+            (void)fast_varint((uint64_t)ring.read32(at + shape.n_len + 1 + shape.wts), o_used, late.od);  // (a fifth byte: another width)
+            diff |= o_used ^ shape.wod;
         }
         uint64_t fits = __ballot((uint32_t)lane < m && diff == 0);
         return uni(~fits ? (uint32_t)__ffsll((long long)~fits) - 1 : 64);
@@ -1148,7 +1200,8 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                 if (!in) start = 0, at = bias;
                 int32_t len = 0;
                 uint32_t used = 0;
-                bool ok = in && fast_varint(ring.read64(at), used, len);
+                uint64_t len_bytes = ring.read64(at);
+                bool ok = in && fast_varint(len_bytes, used, len);
                 // the whole record lies inside the data (this also catches a varint cut short)
                 ok = ok && len >= 0 && (uint64_t)start + used + (uint32_t)len <= data_len;
                 uint32_t size = ok ? used + (uint32_t)len : 0;
@@ -1164,22 +1217,41 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                 } else {
                     // ---- which of them have the shape in hand; learn the first one's if it has not
                     m = fitting(at, same_size);
+                    if (m == 0 && shape.n_checks && uni(used) <= 4) {
+                        // The record at `pos` may differ from the shape only in its head: deltas a
+                        // byte wider (or narrower) and a length that grew by as much.  Then the rest
+                        // of the shape stands, that much further on: take the head's scalars from
+                        // this record and test again.  (A shape that does not fit after that is
+                        // learnt below like any other: nothing is taken on trust here either.)
+                        uint32_t n_len = uni(used);
+                        int32_t length = (int32_t)uni((uint32_t)len);
+                        uint32_t t_used, o_used;
+                        int64_t ts;
+                        int32_t od;
+                        uint64_t r1 = ring.read40(RingCfg<kRows>::wrap(at + n_len));
+                        bool head = fast_varlong((uint32_t)(r1 >> 8), t_used, ts);
+                        head = fast_varint((uint64_t)ring.read32(at + n_len + 1 + t_used), o_used, od) && head && o_used <= 4;
+                        uint32_t wts = uni(t_used), wod = uni(o_used);
+                        int32_t grown = (int32_t)(wts + wod) - (int32_t)(shape.wts + shape.wod);
+                        if (uni((uint32_t)head) && length == shape.length + grown) {
+                            uint32_t moved = (uint32_t)grown + n_len - shape.n_len;  // (wraps when the head shrank)
+                            shape.n_len = n_len;
+                            shape.length = length;
+                            shape.wts = wts;
+                            shape.wod = wod;
+                            shape.o_fix += moved;
+                            shape.o_key += moved;
+                            shape.o_val += moved;
+                            shape.size = S;
+                            shape.lenpat = uni((uint32_t)len_bytes) & shape.lenmask();
+                            m = fitting(at, same_size);
+                        }
+                    }
                     if (m == 0) {
                         if (lane == 0) learn_shape(tab, ring, pos + bias, S);
                         lds_order();
-                        const lds_u128 *in4 = htab + kShapeHdrs;
-                        u32x4 a = in4[0], b4 = in4[1], c4 = in4[2];
-                        st = (int)uni(c4.y);
-                        shape.n_checks = st == kWalkDone ? uni(a.x) : 0;
+                        st = load_shape();
                         shape.size = S;
-                        shape.n_len = uni(a.y);
-                        shape.length = (int32_t)uni(a.z);
-                        shape.o_od = uni(a.w);
-                        shape.o_key = uni(b4.x);
-                        shape.o_val = uni(b4.y);
-                        shape.klen = (int32_t)uni(b4.z);
-                        shape.vlen = (int32_t)uni(b4.w);
-                        shape.hc = uni(c4.x);
                         m = fitting(at, same_size);
                         if (st == kWalkDone && m == 0) st = kWalkExact;  // cannot happen: a record fits its own shape
                     }
@@ -1202,14 +1274,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         }
         PHASE(5)
         if (m) {
-            // ---- the free fields of the records that fit
-            uint32_t w_used;
-            int64_t ts;
-            uint64_t r1 = ring.read64(at + shape.n_len);  // attributes, then the timestamp delta
-            late.attributes = (uint32_t)r1 & 0xffu;
-            fast_varlong((uint32_t)(r1 >> 8), w_used, ts);
-            late.ts = (int32_t)ts;  // a shape's timestamp delta has at most four bytes
-            fast_varint(ring.read64(at + shape.o_od), w_used, late.od);
+            // ---- (the free fields of the records that fit were read when they were tested)
             late.slot = 0;
             late.piece = slots.next;
             late.headers = shape.hc ? slots.take_uniform(shape.hc, m, lane, late.slot) : false;
