@@ -73,6 +73,9 @@ struct Work {
     uint64_t *tile_sum;     // the scans over very many batches: two sums a tile of kScanTile batches
     uint32_t *shape_guess;  // kShapeWords words a block of kSumBlock batches: the shape of the first record of the block's first batch (guess_shape)
     uint32_t *chunk_done;   // encode: the CRC work item has its residue already (from the copy of a long span)
+    // Two words of page-locked host memory that the call leaves for the host's next call: [0] the entries
+    // its list had, [1] the CRC work items its large batches have (or would have had).  May be NULL.
+    uint32_t *hint;
 };
 
 constexpr uint32_t kBigChunks = 8;        // from this many 64 KiB chunks on a batch's CRC is taken chunk by chunk
@@ -145,7 +148,7 @@ __device__ inline uint64_t block_exclusive_scan64(uint64_t v, uint64_t *lds, uin
 // it is expected to need (high half).
 __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t *batch_off, uint32_t b, int by_value,
                                             const nisshi_columns &c, const Work &w, uint32_t count_small,
-                                            uint32_t seg_chunks, uint32_t &chunk_items) {
+                                            uint32_t seg_chunks, bool chunks_on, uint32_t &chunk_items) {
     const uint8_t *p = blob + batch_off[b];
     uint64_t len = batch_off[b + 1] - batch_off[b];
     int st = NISSHI_OK;
@@ -301,8 +304,10 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
     // large batch of anything else gets its CRC from its chunks and its records
     // from one wave.  Either way its chunks are work items.
     bool segmented = fits && chunks >= seg_chunks && first_size != 0 && first_size <= kSegRecordMax;
+    // (chunks_on false: the call has no launch that works on chunks -- the call before it had no such
+    // batch; the items are still counted, for the call after this one, and the batch is one wave's)
     chunk_items = segmented || chunks >= kBigChunks ? chunks : 0;
-    if (chunk_items) w.flags[b] |= segmented ? kFlagSeg | kFlagChunks : kFlagChunks;
+    if (chunk_items && chunks_on) w.flags[b] |= segmented ? kFlagSeg | kFlagChunks : kFlagChunks;
     w.hdr_need[b] = 0;
     return ((uint64_t)expect << 32) | (fits ? record_count : 0u);
 }
@@ -312,7 +317,8 @@ __device__ inline void guess_shape(const uint8_t *blob, const uint64_t *batch_of
 // The workgroups past the blocks' (one a block, launched when w.shape_guess is
 // there) each leave a guess at the shape of their block's records: guess_shape.
 __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
-                                    int by_value, nisshi_columns c, Work w, uint32_t count_small, uint32_t seg_chunks) {
+                                    int by_value, nisshi_columns c, Work w, uint32_t count_small, uint32_t seg_chunks,
+                                    uint32_t chunks_on) {
     __shared__ uint64_t wave_sums[kSumBlock >> 6];
     uint32_t n_blocks = (n + kSumBlock - 1) / kSumBlock;
     if (blockIdx.x >= n_blocks) {
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *
     if (b < 8) w.totals[b] = 0;
     uint64_t mine = 0;  // record slots in the low half, expected header slots in the high half
     uint32_t items = 0;  // CRC work items: those of large batches
-    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, seg_chunks, items);
+    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, seg_chunks, chunks_on != 0, items);
     uint64_t total;
     uint64_t before = block_exclusive_scan64(mine, wave_sums, total);
     if (b < n) {
@@ -1275,7 +1281,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         PHASE(5)
         if (m) {
             // ---- (the free fields of the records that fit were read when they were tested)
-            late.slot = 0;
+            late.slot = slots.next;  // (a record without headers notes where its headers would have started, as every walk does)
             late.piece = slots.next;
             late.headers = shape.hc ? slots.take_uniform(shape.hc, m, lane, late.slot) : false;
             if (slots.full) {
@@ -1670,7 +1676,7 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
         // a header is at least two bytes: a count the record cannot hold is an error
         ok = ok && f.hdr_count >= 0 && o <= body && (uint32_t)f.hdr_count <= (body - o) / 2;
         uint32_t hc = live && ok ? (uint32_t)f.hdr_count : 0;
-        uint32_t slot = 0;
+        uint32_t slot = slots.next;  // (a round without headers: where they would have started, as every walk notes it)
         bool no_room = false;
         PHASE(4)
         if (__any(hc != 0)) {
@@ -2216,6 +2222,19 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
 #endif
 }
 
+// What a call leaves in page-locked memory for the host's next call on the context:
+// how many batches it listed, and how many CRC work items its large batches have.
+// By one wave, when the list is complete.
+__device__ __forceinline__ void leave_hints(const Work &w, uint32_t n, bool prefixed, int lane, uint32_t entries) {
+    if (w.hint == nullptr) return;
+    ChunkItems items;
+    items.init(w, n, prefixed, lane);
+    if (lane == 0) {
+        w.hint[0] = entries;
+        w.hint[1] = items.total;
+    }
+}
+
 // The chunks of large batches, a wave each (as many passes as the grid needs),
 // ahead of decode_fused_kernel: of a batch of small records a chunk's wave takes
 // the chunk's share of the CRC and of the records (see segments_join), of any
@@ -2371,11 +2390,13 @@ __global__ __launch_bounds__(256) void tiny_batch_kernel(const uint8_t *blob, co
 // those of all batches.
 template <int kRows>
 __global__ __launch_bounds__(64) void second_pass_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
-                                                         nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap) {
+                                                         nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap,
+                                                         uint32_t prefixed) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
     __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
     int lane = threadIdx.x & 63;
     uint32_t entries = (uint32_t)w.totals[7];
+    if (blockIdx.x == 0) leave_hints(w, n, prefixed != 0, lane, entries);
     for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
         uint32_t b = uni(w.list[e]);
         uint32_t flags = uni(w.flags[b]);
