@@ -233,19 +233,21 @@ typedef __attribute__((address_space(3))) u32x4 lds_u128;
 // reduced through the byte-wise tables, staged in `tab` first, instead of bit by
 // bit (128 dependent steps of three instructions), and the lane's weight comes
 // with the padding already divided out (a multiplication less).
-__device__ __forceinline__ uint32_t crc_row_residue_staged(const uint32_t (&a)[4], int lane, const CrcTables *t,
-                                                           uint32_t pad, lds_u32 *tab) {
+__device__ __forceinline__ void crc_stage_tables(lds_u32 *tab, const CrcTables *t, int lane) {
     typedef __attribute__((address_space(1))) const u32x4 gbl_u128;
-    typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
     gbl_u128 *src = (gbl_u128 *)(uintptr_t)&t->slice[0][0];
     u32x4 q0 = src[lane], q1 = src[64 + lane], q2 = src[128 + lane], q3 = src[192 + lane];
-    uint32_t weight = ((gbl_u32 *)(uintptr_t)&t->lane_pad_weight[0][0])[pad * 64 + (uint32_t)lane];
     lds_u128 *dst = (lds_u128 *)tab;
     dst[lane] = q0;
     dst[64 + lane] = q1;
     dst[128 + lane] = q2;
     dst[192 + lane] = q3;
     asm volatile("" ::: "memory");
+}
+
+// The residue of an accumulator row through byte tables that crc_stage_tables has
+// put in `tab`; `weight`: the lane's weight in the row (with any padding divided out).
+__device__ __forceinline__ uint32_t crc_row_residue_tab(const uint32_t (&a)[4], uint32_t weight, const lds_u32 *tab) {
     uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -253,6 +255,14 @@ __device__ __forceinline__ uint32_t crc_row_residue_staged(const uint32_t (&a)[4
         c = xor3(tab[768 + (c & 0xffu)], tab[512 + ((c >> 8) & 0xffu)], tab[256 + ((c >> 16) & 0xffu)]) ^ tab[c >> 24];
     }
     return wave_xor(gf_mulmod(c, weight));
+}
+
+__device__ __forceinline__ uint32_t crc_row_residue_staged(const uint32_t (&a)[4], int lane, const CrcTables *t,
+                                                           uint32_t pad, lds_u32 *tab) {
+    typedef __attribute__((address_space(1))) const uint32_t gbl_u32;
+    uint32_t weight = ((gbl_u32 *)(uintptr_t)&t->lane_pad_weight[0][0])[pad * 64 + (uint32_t)lane];
+    crc_stage_tables(tab, t, lane);
+    return crc_row_residue_tab(a, weight, tab);
 }
 
 // Byte mask of a little-endian word at absolute address `addr`: keep the bytes in [lo, hi).
