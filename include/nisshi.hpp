@@ -70,11 +70,11 @@ struct Error {
         TryFromInt,              // negative batch_length
         UnknownCompressionType,  // detail = attributes & 7
         Malformed,               // the reference panics on this input (codec.rs:70-74, 291-295; record.rs:260)
-        Compressed,              // a zstd batch: not decoded by the device codec
+        Compressed,              // a batch that is still compressed: the decode entry points take uncompressed batches (inflate first)
         Capacity,
         Device,
         InvalidArgument,
-        Inflate,                 // gzip, Snappy or LZ4 record data that does not inflate (the inflator's Error::Snap / Error::Io)
+        Inflate,                 // gzip, Snappy, LZ4 or zstd record data that does not inflate (the inflator's Error::Snap / Error::Io)
         InflatedRecords,         // record data that inflated but whose records do not decode: the reference reads
                                  // them through serde over the inflator's reader (deflated.rs:444-457) and returns
                                  // Err (Error::Io or Error::Message) -- it never panics there; detail = the decode's status
@@ -487,11 +487,11 @@ inline Result<inflated::Frame> inflate(Codec &codec, const deflated::Frame &fram
         off[b + 1] = blob.size();
         rec_cap += frame.batches[b].record_count;
     }
-    // gzip, Snappy and LZ4 batches: the frame with them rewritten as uncompressed batches first
-    // (Compression::inflator, lib.rs:1716-1755, as deflated.rs:444-457 calls it)
+    // gzip, Snappy, LZ4 and zstd batches: the frame with them rewritten as uncompressed batches first
+    // (Compression::inflator, lib.rs:1716-1765, as deflated.rs:444-457 calls it)
     std::vector<int32_t> inflated_status(nb ? nb : 1, NISSHI_NONE);
     bool compressed = false;
-    for (const auto &d : frame.batches) compressed = compressed || ((d.attributes & 7) >= 1 && (d.attributes & 7) <= 3);
+    for (const auto &d : frame.batches) compressed = compressed || ((d.attributes & 7) >= 1 && (d.attributes & 7) <= 4);
     if (compressed) {
         std::vector<uint64_t> out_off(nb + 1, 0);
         nisshi_totals room{};

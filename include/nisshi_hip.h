@@ -495,18 +495,18 @@ typedef int (*nisshi_pool_decode_fn)(void *decoder_ctx, const uint8_t *blob, uin
 int nisshi_hip_pool_create_custom(uint32_t n_devices, nisshi_pool_decode_fn decode, void *const *decoder_ctx,
                                   nisshi_hip_pool **pool);
 
-/* ---- compressed batches: gzip, Snappy and LZ4 (Compression::inflator, nisshi-sans-io/src/lib.rs:1716-1755,
+/* ---- compressed batches: gzip, Snappy, LZ4 and zstd (Compression::inflator, nisshi-sans-io/src/lib.rs:1716-1765,
  * as called by Vec<Record>::try_from(deflated::Batch), nisshi-sans-io/src/record/deflated.rs:444-457).
  * The reference inflates a compressed batch's record data and deserializes the records from the
  * result.  This call rewrites a frame: every batch of d_blob in order; a batch whose header passes
- * the checks of deflated::Batch::try_from(Bytes) (deflated.rs:108-213), whose codec is gzip, Snappy
- * or LZ4 (attributes & 7 in 1..3) and whose record data inflates becomes an uncompressed batch --
+ * the checks of deflated::Batch::try_from(Bytes) (deflated.rs:108-213), whose codec is gzip, Snappy,
+ * LZ4 or zstd (attributes & 7 in 1..4) and whose record data inflates becomes an uncompressed batch --
  * its 61 header bytes with batch_length = 49 + inflated length and the codec bits of attributes
  * cleared (inflated::Batch::try_from clears them, inflated.rs:123-140; the crc field stays the
  * compressed batch's, as the reference's inflated batch carries it: it does not cover the
  * rewritten bytes), then the inflated record data -- with d_status[b] = NISSHI_OK; one that does
  * not inflate is passed through as it is, NISSHI_INFLATE: take the reference's own path for it;
- * every other batch (uncompressed, zstd, a header that does not parse) is passed through,
+ * every other batch (uncompressed, a header that does not parse) is passed through,
  * NISSHI_NONE.  Decoding the output with nisshi_hip_decode_dev gives the records the reference
  * gives for the inflated batches.
  * Snappy: as in the reference the record data is one raw block (the `snap` crate's
@@ -519,7 +519,13 @@ int nisshi_hip_pool_create_custom(uint32_t n_devices, nisshi_pool_decode_fn deco
  * trailer's CRC-32 is not compared (the reference does not read that far).
  * LZ4: one frame as liblz4's LZ4F_decompress reads it (the `lz4` crate's Decoder): linked or
  * independent blocks, stored blocks, block checksums, content size and content checksum; a frame
- * with a dictionary id is refused.  The reference reads a gzip member or an LZ4 frame only as far as
+ * with a dictionary id is refused.
+ * zstd: the frames of the record data as libzstd's stream decoder reads them (the `zstd` crate's
+ * stream::read::Decoder; RFC 8878): stored, repeated-byte and compressed blocks, Huffman-coded
+ * literals in one or four streams, predefined, described, repeated and one-symbol code tables,
+ * repeat offsets, content size and content checksum (XXH64), skippable frames; a frame with a
+ * dictionary id or a window beyond the stream decoder's default limit (128 MiB) is refused.
+ * The reference reads a gzip member, an LZ4 frame or a zstd frame only as far as
  * its records need it; here the whole of it must be sound, so one that is damaged behind its last record is
  * NISSHI_INFLATE here and Ok there: the reference's own path, which the status asks for, gives
  * its result.
@@ -527,11 +533,11 @@ int nisshi_hip_pool_create_custom(uint32_t n_devices, nisshi_pool_decode_fn deco
  * d_out_off receives n_batches + 1 offsets into d_out.  With d_out == NULL the call only says how
  * much room the output needs: totals->out_bytes is a capacity that holds it whatever the blocks
  * turn out to be (each batch counted at the larger of its own size and what its Snappy block or
- * gzip member announces, an LZ4 batch with what its frame's blocks can hold at most; a block that announces more than 22 bytes
+ * gzip member announces, an LZ4 or zstd batch with what its frames' blocks can hold at most; a block that announces more than 22 bytes
  * a byte of its own cannot inflate and is not counted so); d_status and d_out_off are not final then.  Otherwise a d_out of out_cap bytes (16-byte
  * aligned) receives the frame; NISSHI_CAPACITY when out_cap is below that capacity.  The output
- * is laid out by what the blocks announce and written by one walk over them (LZ4 frames, which
- * announce nothing, are walked into a scratch area of the context first and copied from there);
+ * is laid out by what the blocks announce and written by one walk over them (LZ4 and zstd frames,
+ * which need not announce anything, are walked into a scratch area of the context first and copied from there);
  * only when a block then does not inflate is the output laid out and written a second time, with
  * that batch passed through.
  * totals (not NULL: the call waits) has out_bytes, the bytes of the frame, and n_failed, the

@@ -1661,6 +1661,591 @@ int no_gzip_member(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t
     return NO_OK;
 }
 
+/* ------------------------------------------------------------------ zstd
+ * Compression::inflator's Zstd arm (nisshi-sans-io/src/lib.rs:1756-1765): zstd::stream::read::Decoder of the
+ * zstd crate (0.13.2 in Cargo.lock, which builds libzstd; neither is vendored) over the record data.  Restated
+ * from the published format (RFC 8878): frames of blocks; a compressed block is a literals section (raw, one
+ * byte repeated, or Huffman coded in one or four streams read backwards) and a sequences section (literal
+ * length, match length and offset codes from three FSE tables, interleaved in one stream read backwards).
+ * The reference reads the stream as far as its records need it; here, as for the other codecs, every frame
+ * of the record data must be sound. */
+
+static uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | (uint64_t)le32(p + 4) << 32; }
+static uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+/* XXH64, of which a frame's content checksum is the low 32 bits */
+uint64_t no_xxh64(const uint8_t *p, size_t len, uint64_t seed) {
+    const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P3 = 1609587929392839161ull,
+                   P4 = 9650029242287828579ull, P5 = 2870177450012600261ull;
+    const uint8_t *end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v[4] = {seed + P1 + P2, seed + P2, seed, seed - P1};
+        do {
+            for (int i = 0; i < 4; i++) {
+                v[i] = rotl64(v[i] + le64(p) * P2, 31) * P1;
+                p += 8;
+            }
+        } while (p + 32 <= end);
+        h = rotl64(v[0], 1) + rotl64(v[1], 7) + rotl64(v[2], 12) + rotl64(v[3], 18);
+        for (int i = 0; i < 4; i++) h = (h ^ (rotl64(v[i] * P2, 31) * P1)) * P1 + P4;
+    } else {
+        h = seed + P5;
+    }
+    h += len;
+    for (; p + 8 <= end; p += 8) h = rotl64(h ^ (rotl64(le64(p) * P2, 31) * P1), 27) * P1 + P4;
+    if (p + 4 <= end) {
+        h = rotl64(h ^ (le32(p) * P1), 23) * P2 + P3;
+        p += 4;
+    }
+    for (; p < end; p++) h = rotl64(h ^ (*p * P5), 11) * P1;
+    h ^= h >> 33;
+    h *= P2;
+    h ^= h >> 29;
+    h *= P3;
+    h ^= h >> 32;
+    return h;
+}
+
+static int zs_top_bit(uint32_t v) { /* index of the highest set bit; v != 0 */
+    int i = 0;
+    while (v >>= 1) i++;
+    return i;
+}
+
+/* bits read forwards, the lowest bit of a byte first (the FSE table descriptions) */
+typedef struct {
+    const uint8_t *p;
+    size_t n, bit;
+    int bad;
+} zs_fwd;
+
+static uint32_t zs_fwd_bits(zs_fwd *r, int nb) {
+    uint32_t v = 0;
+    for (int i = 0; i < nb; i++) {
+        size_t at = r->bit + (size_t)i;
+        if ((at >> 3) >= r->n) {
+            r->bad = 1;
+            break;
+        }
+        v |= (uint32_t)((r->p[at >> 3] >> (at & 7)) & 1) << i;
+    }
+    r->bit += (size_t)nb;
+    return v;
+}
+
+/* bits read backwards: the stream's last byte holds a marker, its highest set bit, below which the data starts;
+ * `bit` counts the bits still unread and goes negative when more are asked for than there are (those read as 0) */
+typedef struct {
+    const uint8_t *p;
+    int64_t bit;
+} zs_back;
+
+static int zs_back_init(zs_back *r, const uint8_t *p, size_t n) {
+    if (n == 0 || p[n - 1] == 0) return -1;
+    r->p = p;
+    r->bit = (int64_t)(n - 1) * 8 + zs_top_bit(p[n - 1]);
+    return 0;
+}
+
+static uint64_t zs_back_bits(zs_back *r, int nb) {
+    uint64_t v = 0;
+    r->bit -= nb;
+    for (int i = nb - 1; i >= 0; i--) {
+        int64_t at = r->bit + i;
+        v = (v << 1) | (uint64_t)(at >= 0 ? (r->p[at >> 3] >> (at & 7)) & 1 : 0);
+    }
+    return v;
+}
+
+/* an FSE decoding table: the symbol a state stands for, and the state that follows it: base + that many bits */
+typedef struct {
+    uint8_t sym[512], nbits[512];
+    uint16_t base[512];
+    int log; /* -1: none yet (a block that asks to repeat it is damaged) */
+} zs_fse;
+
+static int zs_fse_build(zs_fse *t, const int16_t *freq, int n_sym, int log) {
+    int size = 1 << log, high = size;
+    uint16_t next[256];
+    for (int s = 0; s < n_sym; s++)
+        if (freq[s] == -1) {
+            t->sym[--high] = (uint8_t)s;
+            next[s] = 1;
+        }
+    int step = (size >> 1) + (size >> 3) + 3, mask = size - 1, pos = 0;
+    for (int s = 0; s < n_sym; s++) {
+        if (freq[s] <= 0) continue;
+        next[s] = (uint16_t)freq[s];
+        for (int i = 0; i < freq[s]; i++) {
+            t->sym[pos] = (uint8_t)s;
+            do pos = (pos + step) & mask;
+            while (pos >= high);
+        }
+    }
+    if (pos != 0) return -1;
+    for (int i = 0; i < size; i++) {
+        uint16_t x = next[t->sym[i]]++;
+        t->nbits[i] = (uint8_t)(log - zs_top_bit(x));
+        t->base[i] = (uint16_t)((x << t->nbits[i]) - size);
+    }
+    t->log = log;
+    return 0;
+}
+
+/* a table description (RFC 8878, 4.1.1): the accuracy log, then a count a symbol in as many bits as what is
+ * left of the table can need, a run of zero counts by two-bit repeat flags; ends on a byte boundary */
+static int zs_fse_describe(const uint8_t *p, size_t n, int max_log, int max_sym, zs_fse *t, size_t *used) {
+    zs_fwd r = {p, n, 0, 0};
+    int log = 5 + (int)zs_fwd_bits(&r, 4);
+    if (log > max_log) return -1;
+    int left = 1 << log, n_sym = 0;
+    int16_t freq[256];
+    while (left > 0 && n_sym < max_sym) {
+        int bits = zs_top_bit((uint32_t)left + 1) + 1;
+        uint32_t v = zs_fwd_bits(&r, bits);
+        uint32_t low = (1u << (bits - 1)) - 1, few = (1u << bits) - 1 - ((uint32_t)left + 1);
+        if ((v & low) < few) {
+            r.bit -= 1;
+            v &= low;
+        } else if (v > low) {
+            v -= few;
+        }
+        int count = (int)v - 1;
+        left -= count < 0 ? 1 : count;
+        freq[n_sym++] = (int16_t)count;
+        if (count == 0) {
+            for (;;) {
+                uint32_t more = zs_fwd_bits(&r, 2);
+                for (uint32_t i = 0; i < more && n_sym < max_sym; i++) freq[n_sym++] = 0;
+                if (more != 3 || r.bad) break;
+            }
+        }
+        if (r.bad) return -1;
+    }
+    if (left != 0 || r.bad) return -1;
+    *used = (r.bit + 7) >> 3;
+    if (*used > n) return -1;
+    return zs_fse_build(t, freq, n_sym, log);
+}
+
+/* the literals' Huffman code as a table over the next max_bits bits */
+typedef struct {
+    uint8_t sym[2048], nbits[2048];
+    int max_bits; /* 0: none yet */
+} zs_huf;
+
+static int zs_huf_build(zs_huf *h, uint8_t *weight, int n) { /* n weights; the last symbol's follows from them */
+    uint32_t sum = 0;
+    for (int i = 0; i < n; i++) {
+        if (weight[i] > 11) return -1;
+        sum += weight[i] ? 1u << (weight[i] - 1) : 0;
+    }
+    if (sum == 0 || n >= 256) return -1;
+    int max_bits = zs_top_bit(sum) + 1;
+    uint32_t left = (1u << max_bits) - sum;
+    if (max_bits > 11 || (left & (left - 1))) return -1;
+    weight[n++] = (uint8_t)(zs_top_bit(left) + 1);
+    uint32_t start[13] = {0}, count[13] = {0};
+    for (int i = 0; i < n; i++) count[weight[i]]++;
+    for (int w = 1, at = 0; w <= max_bits; w++) {
+        start[w] = (uint32_t)at;
+        at += (int)(count[w] << (w - 1));
+    }
+    for (int s = 0; s < n; s++) {
+        int w = weight[s];
+        if (!w) continue;
+        for (uint32_t i = 0; i < (1u << (w - 1)); i++) {
+            h->sym[start[w] + i] = (uint8_t)s;
+            h->nbits[start[w] + i] = (uint8_t)(max_bits + 1 - w);
+        }
+        start[w] += 1u << (w - 1);
+    }
+    h->max_bits = max_bits;
+    return 0;
+}
+
+/* the tree description (4.2.1): weights as nibbles, or FSE coded with two states taking turns */
+static int zs_huf_describe(const uint8_t *p, size_t n, zs_huf *h, size_t *used) {
+    uint8_t weight[256];
+    int count = 0;
+    if (n < 1) return -1;
+    int head = p[0];
+    if (head >= 128) {
+        count = head - 127;
+        size_t bytes = ((size_t)count + 1) / 2;
+        if (n < 1 + bytes) return -1;
+        for (int i = 0; i < count; i++) weight[i] = i & 1 ? p[1 + i / 2] & 15 : p[1 + i / 2] >> 4;
+        *used = 1 + bytes;
+    } else {
+        if (head == 0 || n < 1 + (size_t)head) return -1;
+        zs_fse t;
+        size_t hdr = 0;
+        if (zs_fse_describe(p + 1, (size_t)head, 6, 256, &t, &hdr)) return -1;
+        zs_back r;
+        if (zs_back_init(&r, p + 1 + hdr, (size_t)head - hdr)) return -1;
+        uint32_t s1 = (uint32_t)zs_back_bits(&r, t.log), s2 = (uint32_t)zs_back_bits(&r, t.log);
+        if (r.bit < 0) return -1;
+        for (;;) {
+            if (count > 253) return -1;
+            weight[count++] = t.sym[s1];
+            s1 = t.base[s1] + (uint32_t)zs_back_bits(&r, t.nbits[s1]);
+            if (r.bit < 0) {
+                weight[count++] = t.sym[s2];
+                break;
+            }
+            weight[count++] = t.sym[s2];
+            s2 = t.base[s2] + (uint32_t)zs_back_bits(&r, t.nbits[s2]);
+            if (r.bit < 0) {
+                weight[count++] = t.sym[s1];
+                break;
+            }
+        }
+        *used = 1 + (size_t)head;
+    }
+    return zs_huf_build(h, weight, count);
+}
+
+static int zs_huf_stream(const zs_huf *h, const uint8_t *p, size_t n, uint8_t *out, size_t want) {
+    zs_back r;
+    if (zs_back_init(&r, p, n)) return -1;
+    uint32_t mask = (1u << h->max_bits) - 1, state = (uint32_t)zs_back_bits(&r, h->max_bits);
+    size_t got = 0;
+    while (r.bit > -(int64_t)h->max_bits) {
+        if (got == want) return -1;
+        out[got++] = h->sym[state];
+        int nb = h->nbits[state];
+        state = ((state << nb) + (uint32_t)zs_back_bits(&r, nb)) & mask;
+    }
+    return r.bit == -(int64_t)h->max_bits && got == want ? 0 : -1;
+}
+
+typedef struct {
+    zs_huf huf;
+    zs_fse ll, of, ml;
+    uint32_t rep[3];
+    uint8_t *lit; /* 128 KiB */
+} zs_frame;
+
+static const int16_t zs_ll_default[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                          2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+static const int16_t zs_of_default[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+static const int16_t zs_ml_default[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                          1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+static const uint32_t zs_ll_base[36] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,   10,  11,  12,   13,   14,   15,   16,    18,
+                                        20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+static const uint8_t zs_ll_extra[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static const uint32_t zs_ml_base[53] = {3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                        21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41,
+                                        43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+static const uint8_t zs_ml_extra[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                        0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+
+/* one of the three code tables of a sequences section, by its mode (4.1.1 of the sequences header) */
+static int zs_seq_table(int mode, const uint8_t *p, size_t n, size_t *pos, zs_fse *t, const int16_t *dflt, int dflt_n,
+                        int dflt_log, int max_log, int max_sym) {
+    if (mode == 0) return zs_fse_build(t, dflt, dflt_n, dflt_log);
+    if (mode == 1) {
+        if (*pos >= n || p[*pos] >= max_sym) return -1;
+        t->sym[0] = p[(*pos)++];
+        t->nbits[0] = 0;
+        t->base[0] = 0;
+        t->log = 0;
+        return 0;
+    }
+    if (mode == 2) {
+        size_t used = 0;
+        if (zs_fse_describe(p + *pos, n - *pos, max_log, max_sym, t, &used)) return -1;
+        *pos += used;
+        return 0;
+    }
+    return t->log < 0 ? -1 : 0; /* repeat: the table of the block before */
+}
+
+/* a compressed block (3.1.1.2 - 3.1.1.4): `out` is the frame's output so far, d bytes; block_max bounds what it adds */
+static int zs_block(zs_frame *f, const uint8_t *p, size_t n, uint8_t *out, size_t *d_io, size_t cap, size_t block_max) {
+    if (n < 1) return -1;
+    /* ---- literals */
+    int kind = p[0] & 3, fmt = (p[0] >> 2) & 3;
+    size_t regen, comp = 0, pos, lit_n;
+    const uint8_t *lit;
+    int streams = 1;
+    if (kind < 2) {
+        if (fmt == 0 || fmt == 2) regen = p[0] >> 3, pos = 1;
+        else if (fmt == 1) {
+            if (n < 2) return -1;
+            regen = (size_t)((p[0] | p[1] << 8) >> 4), pos = 2;
+        } else {
+            if (n < 3) return -1;
+            regen = (size_t)((p[0] | p[1] << 8 | p[2] << 16) >> 4), pos = 3;
+        }
+    } else {
+        if (n < 5) return -1;
+        uint64_t h = (uint64_t)p[0] | (uint64_t)p[1] << 8 | (uint64_t)p[2] << 16 | (uint64_t)p[3] << 24 | (uint64_t)p[4] << 32;
+        if (fmt == 0 || fmt == 1) regen = (h >> 4) & 0x3ff, comp = (h >> 14) & 0x3ff, pos = 3;
+        else if (fmt == 2) regen = (h >> 4) & 0x3fff, comp = (h >> 18) & 0x3fff, pos = 4;
+        else regen = (h >> 4) & 0x3ffff, comp = (h >> 22) & 0x3ffff, pos = 5;
+        streams = fmt == 0 ? 1 : 4;
+    }
+    if (regen > block_max) return -1;
+    lit_n = regen;
+    if (kind == 0) {
+        if (n - pos < regen) return -1;
+        lit = p + pos;
+        pos += regen;
+    } else if (kind == 1) {
+        if (n - pos < 1) return -1;
+        memset(f->lit, p[pos], regen);
+        lit = f->lit;
+        pos += 1;
+    } else {
+        if (n - pos < comp) return -1;
+        const uint8_t *q = p + pos;
+        size_t qn = comp;
+        if (kind == 2) {
+            size_t used = 0;
+            if (zs_huf_describe(q, qn, &f->huf, &used)) return -1;
+            q += used, qn -= used;
+        } else if (!f->huf.max_bits) {
+            return -1; /* the tree of the block before: there is none */
+        }
+        if (streams == 1) {
+            if (zs_huf_stream(&f->huf, q, qn, f->lit, regen)) return -1;
+        } else {
+            if (qn < 6) return -1;
+            size_t s1 = (size_t)(q[0] | q[1] << 8), s2 = (size_t)(q[2] | q[3] << 8), s3 = (size_t)(q[4] | q[5] << 8);
+            if (s1 + s2 + s3 > qn - 6) return -1;
+            size_t s4 = qn - 6 - s1 - s2 - s3, each = (regen + 3) / 4;
+            if (3 * each > regen) return -1;
+            const uint8_t *a = q + 6;
+            if (zs_huf_stream(&f->huf, a, s1, f->lit, each) || zs_huf_stream(&f->huf, a + s1, s2, f->lit + each, each) ||
+                zs_huf_stream(&f->huf, a + s1 + s2, s3, f->lit + 2 * each, each) ||
+                zs_huf_stream(&f->huf, a + s1 + s2 + s3, s4, f->lit + 3 * each, regen - 3 * each))
+                return -1;
+        }
+        lit = f->lit;
+        pos += comp;
+    }
+    /* ---- sequences */
+    if (pos >= n) return -1;
+    size_t n_seq = p[pos++];
+    if (n_seq >= 128) {
+        if (n_seq == 255) {
+            if (n - pos < 2) return -1;
+            n_seq = (size_t)p[pos] + ((size_t)p[pos + 1] << 8) + 0x7f00;
+            pos += 2;
+        } else {
+            if (n - pos < 1) return -1;
+            n_seq = ((n_seq - 128) << 8) + p[pos++];
+        }
+    }
+    size_t d = *d_io, d0 = d, lit_at = 0;
+    if (n_seq) {
+        if (pos >= n) return -1;
+        int modes = p[pos++];
+        if (modes & 3) return -1;
+        if (zs_seq_table(modes >> 6, p, n, &pos, &f->ll, zs_ll_default, 36, 6, 9, 36) ||
+            zs_seq_table((modes >> 4) & 3, p, n, &pos, &f->of, zs_of_default, 29, 5, 8, 32) ||
+            zs_seq_table((modes >> 2) & 3, p, n, &pos, &f->ml, zs_ml_default, 53, 6, 9, 53))
+            return -1;
+        zs_back r;
+        if (zs_back_init(&r, p + pos, n - pos)) return -1;
+        uint32_t sl = (uint32_t)zs_back_bits(&r, f->ll.log), so = (uint32_t)zs_back_bits(&r, f->of.log),
+                 sm = (uint32_t)zs_back_bits(&r, f->ml.log);
+        for (size_t i = 0; i < n_seq; i++) {
+            int oc = f->of.sym[so], mc = f->ml.sym[sm], lc = f->ll.sym[sl];
+            if (oc > 31 || mc > 52 || lc > 35) return -1;
+            uint64_t ov = ((uint64_t)1 << oc) + zs_back_bits(&r, oc);
+            size_t ml = zs_ml_base[mc] + (size_t)zs_back_bits(&r, zs_ml_extra[mc]);
+            size_t ll = zs_ll_base[lc] + (size_t)zs_back_bits(&r, zs_ll_extra[lc]);
+            uint64_t off;
+            if (ov > 3) {
+                off = ov - 3;
+                f->rep[2] = f->rep[1], f->rep[1] = f->rep[0], f->rep[0] = (uint32_t)off;
+            } else {
+                uint32_t idx = (uint32_t)ov - 1 + (ll == 0 ? 1u : 0u); /* 0, 1, 2, or 3: the first one less one */
+                if (idx == 0) {
+                    off = f->rep[0];
+                } else {
+                    off = idx < 3 ? f->rep[idx] : (uint64_t)f->rep[0] - 1;
+                    if (idx > 1) f->rep[2] = f->rep[1];
+                    f->rep[1] = f->rep[0];
+                    f->rep[0] = (uint32_t)off;
+                }
+            }
+            if (off == 0 || off > 0xffffffffull) return -1;
+            if (i + 1 < n_seq) {
+                sl = f->ll.base[sl] + (uint32_t)zs_back_bits(&r, f->ll.nbits[sl]);
+                sm = f->ml.base[sm] + (uint32_t)zs_back_bits(&r, f->ml.nbits[sm]);
+                so = f->of.base[so] + (uint32_t)zs_back_bits(&r, f->of.nbits[so]);
+            }
+            if (r.bit < 0) return -1;
+            if (ll > lit_n - lit_at || ll + ml > block_max - (d - d0) || ll + ml > cap - d) return -1;
+            memcpy(out + d, lit + lit_at, ll);
+            d += ll, lit_at += ll;
+            if (off > d) return -1; /* (no dictionary: nothing lies before the frame's first byte) */
+            for (size_t k = 0; k < ml; k++) out[d + k] = out[d + k - off];
+            d += ml;
+        }
+        if (r.bit != 0) return -1;
+    } else if (pos != n) {
+        return -1;
+    }
+    size_t rest = lit_n - lit_at;
+    if (rest > block_max - (d - d0) || rest > cap - d) return -1;
+    memcpy(out + d, lit + lit_at, rest);
+    *d_io = d + rest;
+    return 0;
+}
+
+/* a frame's header (3.1.1.1); returns its bytes, 0 when it is not one this decoder takes */
+static size_t zs_header(const uint8_t *in, size_t n, uint64_t *window, int *has_sum, int *has_size, uint64_t *content) {
+    if (n < 6 || le32(in) != 0xFD2FB528u) return 0;
+    int fhd = in[4], single = (fhd >> 5) & 1, did = fhd & 3, fcs = fhd >> 6;
+    if (fhd & 0x08) return 0; /* the reserved bit */
+    size_t s = 5;
+    *window = 0;
+    if (!single) {
+        int wd = in[s++];
+        uint64_t base = (uint64_t)1 << (10 + (wd >> 3));
+        *window = base + (base >> 3) * (uint64_t)(wd & 7);
+    }
+    static const int did_bytes[4] = {0, 1, 2, 4};
+    if (n < s + (size_t)did_bytes[did]) return 0;
+    uint32_t dict = 0;
+    for (int i = 0; i < did_bytes[did]; i++) dict |= (uint32_t)in[s + (size_t)i] << (8 * i);
+    s += (size_t)did_bytes[did];
+    if (dict) return 0; /* a dictionary this decoder does not have */
+    int fcs_bytes = fcs == 0 ? single : 1 << fcs;
+    if (n < s + (size_t)fcs_bytes) return 0;
+    *has_size = fcs_bytes != 0;
+    *content = 0;
+    for (int i = 0; i < fcs_bytes; i++) *content |= (uint64_t)in[s + (size_t)i] << (8 * i);
+    if (fcs_bytes == 2) *content += 256;
+    s += (size_t)fcs_bytes;
+    if (single) *window = *content;
+    *has_sum = (fhd >> 2) & 1;
+    if (*window > ((uint64_t)1 << 27)) return 0; /* the stream decoder's default limit on the window (ZSTD_WINDOWLOG_LIMIT_DEFAULT) */
+    return s;
+}
+
+/* Room that holds what the frames of the record data can regenerate: every raw or repeated block at its size, every
+ * compressed block at the maximal block size.  0: the headers do not chain up to the end of the data. */
+size_t no_zstd_room(const uint8_t *in, size_t n) {
+    size_t s = 0, room = 0;
+    while (s < n) {
+        if (n - s >= 8 && (le32(in + s) & 0xFFFFFFF0u) == 0x184D2A50u) { /* a skippable frame */
+            uint64_t skip = le32(in + s + 4);
+            if (skip > n - s - 8) return 0;
+            s += 8 + (size_t)skip;
+            continue;
+        }
+        uint64_t window, content;
+        int has_sum, has_size;
+        size_t h = zs_header(in + s, n - s, &window, &has_sum, &has_size, &content);
+        if (!h) return 0;
+        s += h;
+        size_t block_max = window < (128u << 10) ? (size_t)window : (128u << 10);
+        for (;;) {
+            if (n - s < 3) return 0;
+            uint32_t bh = (uint32_t)in[s] | (uint32_t)in[s + 1] << 8 | (uint32_t)in[s + 2] << 16;
+            s += 3;
+            uint32_t type = (bh >> 1) & 3, size = bh >> 3;
+            if (type == 3 || size > block_max) return 0;
+            size_t body = type == 1 ? 1 : size;
+            if (n - s < body) return 0;
+            s += body;
+            room += type == 2 ? block_max : size;
+            if (bh & 1) break;
+        }
+        if (has_sum) {
+            if (n - s < 4) return 0;
+            s += 4;
+        }
+    }
+    return room + 1;
+}
+
+/* cap: at least no_zstd_room */
+int no_zstd_frames(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    *out_len = 0;
+    size_t s = 0, d = 0;
+    zs_frame *f = (zs_frame *)malloc(sizeof *f);
+    uint8_t *lit = (uint8_t *)malloc(128u << 10);
+    int st = NO_OK;
+    while (s < n && st == NO_OK) {
+        if (n - s >= 8 && (le32(in + s) & 0xFFFFFFF0u) == 0x184D2A50u) {
+            uint64_t skip = le32(in + s + 4);
+            if (skip > n - s - 8) st = NO_INFLATE;
+            s += 8 + (size_t)skip;
+            continue;
+        }
+        uint64_t window, content;
+        int has_sum, has_size;
+        size_t h = zs_header(in + s, n - s, &window, &has_sum, &has_size, &content);
+        if (!h) {
+            st = NO_INFLATE;
+            break;
+        }
+        s += h;
+        size_t block_max = window < (128u << 10) ? (size_t)window : (128u << 10);
+        memset(f, 0, sizeof *f);
+        f->lit = lit;
+        f->ll.log = f->of.log = f->ml.log = -1;
+        f->rep[0] = 1, f->rep[1] = 4, f->rep[2] = 8;
+        size_t first = d; /* a frame stands alone: its matches reach back to its own first byte at most */
+        for (;;) {
+            if (n - s < 3) {
+                st = NO_INFLATE;
+                break;
+            }
+            uint32_t bh = (uint32_t)in[s] | (uint32_t)in[s + 1] << 8 | (uint32_t)in[s + 2] << 16;
+            s += 3;
+            uint32_t type = (bh >> 1) & 3, size = bh >> 3;
+            if (type == 3 || size > block_max || n - s < (type == 1 ? 1u : size)) {
+                st = NO_INFLATE;
+                break;
+            }
+            if (type == 0 || type == 1) {
+                if (size > cap - d) {
+                    st = NO_CAPACITY;
+                    break;
+                }
+                if (type == 0) memcpy(out + d, in + s, size);
+                else memset(out + d, in[s], size);
+                d += size;
+                s += type == 0 ? size : 1;
+            } else {
+                size_t fd = d - first;
+                if (cap - d < block_max) {
+                    st = NO_CAPACITY;
+                    break;
+                }
+                if (zs_block(f, in + s, size, out + first, &fd, cap - first, block_max)) {
+                    st = NO_INFLATE;
+                    break;
+                }
+                d = first + fd;
+                s += size;
+            }
+            if (bh & 1) break;
+        }
+        if (st != NO_OK) break;
+        if (has_sum) {
+            if (n - s < 4 || (uint32_t)no_xxh64(out + first, d - first, 0) != le32(in + s)) {
+                st = NO_INFLATE;
+                break;
+            }
+            s += 4;
+        }
+        if (has_size && content != d - first) st = NO_INFLATE;
+    }
+    free(lit);
+    free(f);
+    if (st == NO_OK) *out_len = d;
+    return st;
+}
+
 int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_batches, uint8_t *out,
                      size_t out_cap, uint64_t *out_off, int32_t *status) {
     size_t at = 0;
@@ -1672,7 +2257,7 @@ int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_ba
         no_deflated_batch h;
         int st = no_deflated_parse(p, len, &h);
         int codec = 0;
-        if (st == NO_OK && no_compression(h.attributes, &codec) == NO_OK && codec >= 1 && codec <= 3) {
+        if (st == NO_OK && no_compression(h.attributes, &codec) == NO_OK && codec >= 1 && codec <= 4) {
             size_t hl = 0, got = 0;
             uint64_t want = 0;
             const uint8_t *data = h.record_data;
@@ -1685,6 +2270,20 @@ int no_inflate_frame(const uint8_t *blob, const uint64_t *batch_off, size_t n_ba
                     if (at + 61 + want > out_cap) return NO_CAPACITY;
                     st = no_gzip_member(data, n, out + at + 61, (size_t)want, &got);
                 }
+            } else if (codec == 4) {
+                /* zstd: into room of its own first, as LZ4 (a frame need not say how long it is) */
+                size_t room = no_zstd_room(data, n);
+                uint8_t *tmp = (uint8_t *)malloc(room ? room : 1);
+                st = room ? no_zstd_frames(data, n, tmp, room, &got) : NO_INFLATE;
+                if (st == NO_OK && 49 + (uint64_t)got > 0x7fffffffull) st = NO_INFLATE;
+                if (st == NO_OK) {
+                    if (at + 61 + got > out_cap) {
+                        free(tmp);
+                        return NO_CAPACITY;
+                    }
+                    memcpy(out + at + 61, tmp, got);
+                }
+                free(tmp);
             } else if (codec == 3) {
                 /* LZ4: into room of its own first (a frame does not say how long it is) */
                 size_t room = lz4_frame_room(data, n);

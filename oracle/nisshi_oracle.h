@@ -343,6 +343,17 @@ int no_lz4_frame(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *
  * As for LZ4: the whole member must be sound here, NO_INFLATE otherwise. */
 int no_gzip_member(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
 
+/* Compression::inflator's Zstd arm (nisshi-sans-io/src/lib.rs:1756-1765): the zstd crate's stream Decoder
+ * (libzstd) over the record data, restated from the published format (RFC 8878): every frame of the data
+ * (skippable ones skipped) into `out`; a frame with a dictionary id, a window beyond the stream decoder's
+ * default limit of 128 MiB, a content checksum or content size that the bytes do not meet, or any damage
+ * is NO_INFLATE.  As for LZ4: the whole of the record data must be sound here.  no_zstd_room: a `cap` that
+ * suffices (0: the frame and block headers do not chain up to the end of the data).  no_xxh64: XXH64, of
+ * which a frame's content checksum is the low half. */
+size_t no_zstd_room(const uint8_t *in, size_t n);
+int no_zstd_frames(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+uint64_t no_xxh64(const uint8_t *p, size_t len, uint64_t seed);
+
 /* A frame with its gzip, Snappy and LZ4 batches inflated: every batch of blob in order; one that parses
  * (no_deflated_parse) with codec 1, 2 or 3 (no_compression) and inflates becomes
  *   its 61 header bytes with batch_length = 49 + inflated length and the codec bits of

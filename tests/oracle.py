@@ -84,6 +84,11 @@ def _load():
     lib.no_snappy_inflate.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
     lib.no_inflate_frame.argtypes = [vp, vp, sz, vp, sz, vp, vp]
     lib.no_lz4_frame.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
+    lib.no_zstd_frames.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
+    lib.no_zstd_room.argtypes = [u8p, sz]
+    lib.no_zstd_room.restype = sz
+    lib.no_xxh64.argtypes = [u8p, sz, ctypes.c_uint64]
+    lib.no_xxh64.restype = ctypes.c_uint64
     lib.no_gzip_member.argtypes = [u8p, sz, vp, sz, ctypes.POINTER(sz)]
     lib.no_xxh32.argtypes = [u8p, sz, ctypes.c_uint32]
     lib.no_xxh32.restype = ctypes.c_uint32
@@ -120,6 +125,22 @@ def lz4_inflate(data: bytes):
     return st, out.raw[:n.value]
 
 
+def zstd_inflate(data: bytes):
+    """(status, inflated bytes) of the record data of a zstd batch (its frames, one after the other)."""
+    data = bytes(data)
+    room = LIB.no_zstd_room(data, len(data))
+    if room == 0:
+        return 11, b""
+    out = ctypes.create_string_buffer(room)
+    n = ctypes.c_size_t()
+    st = LIB.no_zstd_frames(data, len(data), out, room, ctypes.byref(n))
+    return st, out.raw[:n.value]
+
+
+def xxh64(data: bytes, seed: int = 0) -> int:
+    return LIB.no_xxh64(bytes(data), len(data), seed)
+
+
 def xxh32(data: bytes, seed: int = 0) -> int:
     return LIB.no_xxh32(bytes(data), len(data), seed)
 
@@ -129,12 +150,18 @@ def inflate_frame(blob, batch_off, out_cap=None):
     blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
     off = np.ascontiguousarray(batch_off, dtype=np.uint64)
     n_b = len(off) - 1
+    grow = out_cap is None
     out_cap = 1040 * len(blob) + 64 if out_cap is None else out_cap
-    out = np.zeros(max(out_cap, 1), dtype=np.uint8)
-    out_off = np.zeros(n_b + 1, dtype=np.uint64)
-    status = np.zeros(max(n_b, 1), dtype=np.int32)
-    st = LIB.no_inflate_frame(blob.ctypes.data, off.ctypes.data, n_b, out.ctypes.data, out_cap,
-                              out_off.ctypes.data, status.ctypes.data)
+    while True:
+        out = np.zeros(max(out_cap, 1), dtype=np.uint8)
+        out_off = np.zeros(n_b + 1, dtype=np.uint64)
+        status = np.zeros(max(n_b, 1), dtype=np.int32)
+        st = LIB.no_inflate_frame(blob.ctypes.data, off.ctypes.data, n_b, out.ctypes.data, out_cap,
+                                  out_off.ctypes.data, status.ctypes.data)
+        # (a zstd frame of repeated bytes can hold tens of thousands of bytes a byte)
+        if st != 7 or not grow or out_cap >= (1 << 31):
+            break
+        out_cap *= 8
     return st, out[:int(out_off[n_b])].tobytes() if st == 0 else b"", out_off, status[:n_b]
 
 

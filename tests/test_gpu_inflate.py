@@ -83,7 +83,7 @@ def test_mixed_frame_and_streams_that_do_not_inflate(codec):
         struct.pack_into(">i", head, 8, 49 + len(stream))
         batches.append(bytes(head) + stream)
     got, got_off, status = check(codec, batches)
-    assert [int(s) for s in status[:5]] == [hip.NONE, C.OK, hip.NONE, hip.NONE, C.OK]
+    assert [int(s) for s in status[:5]] == [hip.NONE, C.OK, C.OK, hip.NONE, C.OK]   # (the zstd batch inflates too)
     assert all(int(s) == hip.INFLATE for s in status[5:])
 
 

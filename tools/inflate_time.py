@@ -1,7 +1,7 @@
 """Kernel times of the inflate: one batch of a thousand small records (keys, values of words, two headers)
 compressed on the host and repeated COUNT times (8192 by default).  CODEC=lz4 in the environment: an LZ4 frame
 (independent blocks of 64 KiB, no checksums: what Kafka's clients write) instead of a Snappy block; CODEC=gzip: a
-gzip member from zlib at its default level.
+gzip member from zlib at its default level; CODEC=zstd: a frame from libzstd (pyarrow's) at level 3.
 python tools/inflate_time.py [COUNT]"""
 import json, os, struct, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -22,10 +22,13 @@ for i in range(1000):
     headers = [C.Header(b"trace", bytes(rng.integers(0, 256, 8, dtype=np.uint8))), C.Header(b"kind", words[i % 8])]
     records.append(C.Record(0, 0, i, i, b"user-%06d" % int(rng.integers(0, 5000)), value, headers))
 plain = build_batch(dict(base_offset=0, last_offset_delta=999), records)
-lz4 = os.environ.get("CODEC") in ("lz4", "gzip")    # (below: no count of elements)
+lz4 = os.environ.get("CODEC") in ("lz4", "gzip", "zstd")    # (below: no count of elements)
 if os.environ.get("CODEC") == "gzip":
     import gzip_cases
     data = gzip_cases.member(plain[61:])
+elif os.environ.get("CODEC") == "zstd":
+    import zstd_cases
+    data = zstd_cases.without_size(zstd_cases.compress(plain[61:], 3))     # (as a streaming compressor writes it)
 elif lz4:
     import lz4_cases
     data = lz4_cases.frame(plain[61:])
@@ -33,7 +36,7 @@ else:
     data = compress(plain[61:], window=65535)   # (as far back as a Snappy compressor's 64 KiB blocks reach)
 head = bytearray(plain[:61])
 struct.pack_into(">i", head, 8, 49 + len(data))
-struct.pack_into(">h", head, 21, {"gzip": 1, "lz4": 3}.get(os.environ.get("CODEC"), 2))
+struct.pack_into(">h", head, 21, {"gzip": 1, "lz4": 3, "zstd": 4}.get(os.environ.get("CODEC"), 2))
 struct.pack_into(">I", head, 17, oracle.crc32c(bytes(head[21:]) + data))
 batch = bytes(head) + data
 # elements of the stream
