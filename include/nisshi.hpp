@@ -118,6 +118,8 @@ class Result {
 class Codec {
   public:
     explicit Codec(int device = 0) {
+        if (nisshi_hip_abi_version() != NISSHI_HIP_ABI_VERSION)
+            throw std::runtime_error("libnisshi_hip was built from another nisshi_hip.h than this program");
         int st = nisshi_hip_ctx_create(device, &ctx_);
         if (st) throw std::runtime_error(std::string("nisshi_hip_ctx_create: ") + nisshi_hip_status_str(st));
     }
@@ -434,7 +436,7 @@ struct HostColumns {
     std::vector<int64_t> base_offset, base_timestamp, max_timestamp, producer_id, timestamp_delta;
     std::vector<int32_t> batch_length, partition_leader_epoch, last_offset_delta, base_sequence, status;
     std::vector<int8_t> magic;
-    std::vector<uint32_t> crc, record_count, crc_computed, data_len, rec_base, hdr_base, hdr_count;
+    std::vector<uint32_t> crc, record_count, crc_computed, data_len, rec_base, hdr_base, hdr_count, enc_len;
     std::vector<int16_t> attributes, producer_epoch;
     std::vector<uint64_t> data_off;
     std::vector<nisshi_record_key> rkey;
@@ -450,7 +452,7 @@ struct HostColumns {
         batch_length.resize(nb); partition_leader_epoch.resize(nb); last_offset_delta.resize(nb);
         base_sequence.resize(nb); status.resize(nb); magic.resize(nb); crc.resize(nb); record_count.resize(nb);
         crc_computed.resize(nb); data_len.resize(nb); rec_base.resize(nb); hdr_base.resize(nb);
-        hdr_count.resize(nb); attributes.resize(nb); producer_epoch.resize(nb); data_off.resize(nb);
+        hdr_count.resize(nb); enc_len.resize(nb); attributes.resize(nb); producer_epoch.resize(nb); data_off.resize(nb);
         rkey.resize(nr); rval.resize(nr); timestamp_delta.resize(nr); rattributes.resize(nr);
         hdr.resize(nh);
     }
@@ -466,6 +468,7 @@ struct HostColumns {
         c.rec_base = rec_base.data(); c.hdr_base = hdr_base.data(); c.hdr_count = hdr_count.data();
         c.status = status.data(); c.rkey = rkey.data(); c.rval = rval.data();
         c.timestamp_delta = timestamp_delta.data(); c.rattributes = rattributes.data(); c.hdr = hdr.data();
+        c.enc_len = enc_len.data();
         return c;
     }
 };

@@ -117,6 +117,19 @@ typedef struct nisshi_columns {
     uint8_t *rattributes;
     /* per header */
     nisshi_header_span *hdr;
+    /* per batch, optional (may be NULL): one more than the bytes the batch's records encode to as
+     * they stand, 0 when that is not known.  Record::size_in_bytes summed over the batch
+     * (nisshi-sans-io/src/record.rs:200-231) is what the encode works out first; a decode leaves it
+     * here for the batches whose records it found written the shortest way (every varint minimal, as
+     * producers write them: the records then encode to the bytes they were decoded from), and
+     * nisshi_hip_encode_dev takes it from here instead of sizing those records again.  It is a
+     * hint: the decode notes it in calls whose batches average NISSHI_WIDE_RING_FROM bytes and
+     * more (see nisshi_hip_ctx_create), for batches walked by their records' shapes, whole or
+     * chunk by chunk; any other batch has 0 and is sized by the encode as before.  combine,
+     * compact and the fetch seam store 0 for the batches they write.  A caller that changes a
+     * batch's records by hand stores 0 too (or passes NULL): the encode trusts the value, and one
+     * that is less than the records take makes it write past the batch's place in the output. */
+    uint32_t *enc_len;
 } nisshi_columns;
 
 typedef struct nisshi_totals {
@@ -128,6 +141,13 @@ typedef struct nisshi_totals {
 } nisshi_totals;
 
 typedef struct nisshi_hip_ctx nisshi_hip_ctx;
+
+/* The layout of the structs of this header as a number that grows with every
+ * change to them (2: nisshi_columns ends in enc_len).  A binding checks the
+ * library it loaded against the header it was built from before any other call:
+ * a struct one field short makes the library read a pointer that is not there. */
+#define NISSHI_HIP_ABI_VERSION 2
+int nisshi_hip_abi_version(void);
 
 /* Create a context on a HIP device; fails with NISSHI_DEVICE_ERROR when no
  * usable gfx950 device is present.  There is no CPU fallback.  Five settings are

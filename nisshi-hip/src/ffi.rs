@@ -80,6 +80,9 @@ pub struct Columns {
     pub timestamp_delta: *mut i64,
     pub rattributes: *mut u8,
     pub hdr: *mut HeaderSpan,
+    /// Optional (may be null): per batch, the bytes its records encode to plus one where
+    /// the decode found them written the shortest way, else zero.
+    pub enc_len: *mut u32,
 }
 
 #[repr(C)]
@@ -147,7 +150,11 @@ pub type PoolDecodeFn = unsafe extern "C" fn(
     totals: *mut Totals,
 ) -> c_int;
 
+/// `NISSHI_HIP_ABI_VERSION` of the header these declarations follow.
+pub const NISSHI_HIP_ABI_VERSION: c_int = 2;
+
 extern "C" {
+    pub fn nisshi_hip_abi_version() -> c_int;
     pub fn nisshi_hip_ctx_create(device: c_int, ctx: *mut *mut Ctx) -> c_int;
     pub fn nisshi_hip_ctx_destroy(ctx: *mut Ctx);
     pub fn nisshi_hip_status_str(status: c_int) -> *const c_char;

@@ -105,6 +105,9 @@ pub struct HostColumns {
     pub rattributes: Vec<u8>,
     // per header (header.rs:21-29)
     pub hdr: Vec<ffi::HeaderSpan>,
+    /// per batch: encoded bytes of its records plus one where the decode knows them, else zero
+    /// (zero it for a batch whose records are edited before it is encoded again)
+    pub enc_len: Vec<u32>,
 }
 
 impl HostColumns {
@@ -138,6 +141,7 @@ impl HostColumns {
             timestamp_delta: vec![0; r],
             rattributes: vec![0; r],
             hdr: vec![ffi::HeaderSpan::default(); h],
+            enc_len: vec![0; b],
         }
     }
 
@@ -169,6 +173,7 @@ impl HostColumns {
             timestamp_delta: self.timestamp_delta.as_mut_ptr(),
             rattributes: self.rattributes.as_mut_ptr(),
             hdr: self.hdr.as_mut_ptr(),
+            enc_len: self.enc_len.as_mut_ptr(),
         }
     }
 
@@ -199,6 +204,14 @@ impl Drop for Codec {
 impl Codec {
     /// `nisshi_hip_ctx_create`: fails with [`Status::Device`] without a gfx950 GPU (there is no CPU path).
     pub fn new(device: i32) -> Result<Self> {
+        // (a library built from another header would read struct fields that are not there)
+        let abi = unsafe { ffi::nisshi_hip_abi_version() };
+        if abi != ffi::NISSHI_HIP_ABI_VERSION {
+            return Err(Error {
+                status: Status::InvalidArgument,
+                detail: format!("libnisshi_hip has ABI version {abi}, this crate {}", ffi::NISSHI_HIP_ABI_VERSION),
+            });
+        }
         let mut ctx = ptr::null_mut();
         let st = unsafe { ffi::nisshi_hip_ctx_create(device as c_int, &mut ctx) };
         if st != ffi::NISSHI_OK {

@@ -91,7 +91,10 @@ HEADER_GROUPS = [
 DEVICE_ARRAYS = ([(n, dt, 1, 0) for n, dt in BATCH_COLUMNS] +
                  [("rkey", np.int32, 4, 1), ("rval", np.int32, 4, 1),
                   ("timestamp_delta", np.int64, 1, 1), ("rattributes", np.uint8, 1, 1),
-                  ("hdr", np.int32, 4, 2)])
+                  ("hdr", np.int32, 4, 2),
+                  # a batch's record data in bytes plus one where the decode found every varint
+                  # written the shortest way, else zero: what the encoder need not size again
+                  ("enc_len", np.uint32, 1, 0)])
 _FIELD_DTYPE = dict(ALL_COLUMNS)
 
 
@@ -130,6 +133,8 @@ def pack(cols: dict) -> dict:
         out[name] = g
     out["timestamp_delta"] = np.ascontiguousarray(cols["timestamp_delta"])
     out["rattributes"] = np.ascontiguousarray(cols["rattributes"])
+    n = len(cols["status"])
+    out["enc_len"] = np.ascontiguousarray(cols["enc_len"]) if "enc_len" in cols else np.zeros(max(n, 1), np.uint32)
     return out
 
 
@@ -142,6 +147,8 @@ def unpack(arrays: dict) -> dict:
             out[f] = np.ascontiguousarray(g[:, i]).view(_FIELD_DTYPE[f])
     out["timestamp_delta"] = arrays["timestamp_delta"]
     out["rattributes"] = arrays["rattributes"]
+    if "enc_len" in arrays:
+        out["enc_len"] = arrays["enc_len"]
     return out
 
 
@@ -164,6 +171,8 @@ def trim(cols: dict, n_batches: int, n_records: int, n_headers: int) -> dict:
         out[name] = cols[name][:n_records]
     for name, _ in HEADER_COLUMNS:
         out[name] = cols[name][:n_headers]
+    if "enc_len" in cols:
+        out["enc_len"] = cols["enc_len"][:n_batches]
     return out
 
 

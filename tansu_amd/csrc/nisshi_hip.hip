@@ -274,6 +274,7 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
     c.hdr_base[b] = 0;
     c.hdr_count[b] = 0;
     c.status[b] = st;
+    if (c.enc_len) c.enc_len[b] = 0;
     // A record is at least seven bytes, so a count beyond data_len / 7 can only
     // fail: give it no slots and let the sequential walk find the error.
     bool decodable = st == NISSHI_OK;
@@ -796,6 +797,11 @@ struct Shape {
     uint32_t o_key, o_val;  // offsets from the start of the record
     int32_t klen, vlen;
     uint32_t hc;
+    bool minimal;       // every length and count varint from the key's on is written the shortest way
+    __device__ __forceinline__ bool len_minimal() const {  // and so is the record's length
+        uint32_t z = ((uint32_t)length << 1) ^ (uint32_t)(length >> 31);
+        return n_len == (38 - (uint32_t)__clz(z | 1u)) / 7;
+    }
 
     __device__ __forceinline__ uint32_t lenmask() const { return n_len >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * n_len)); }
 };
@@ -862,7 +868,7 @@ struct RingView {
 // Tab: where the table goes (LDS, or global memory for a guess handed to other
 // waves); Src: where the record's bytes come from, read64(position).  kGuard: the
 // source may not be read at or past the record's end (global memory).
-template <bool kGuard, class Tab, class Src>
+template <bool kGuard, bool kMinimal, class Tab, class Src>
 __device__ __forceinline__ int learn_shape_any(Tab tab, Src &ring, uint32_t at0, uint32_t size) {
     Tab htab = tab + kShapeChecks;
     Tab out = htab + kShapeHdrs;
@@ -871,7 +877,7 @@ __device__ __forceinline__ int learn_shape_any(Tab tab, Src &ring, uint32_t at0,
     uint32_t fields = 6;
     uint32_t n_len = 0, wts = 0, wod = 0, o_fix = 0, lenpat = 0, o_key = 0, o_val = 0, hc = 0, ko = 0;
     int32_t length = 0, klen = 0, vlen = 0, kl = 0;
-    bool wide = false, bad = false;
+    bool wide = false, bad = false, minimal = true;
     for (uint32_t i = 0; i < fields && !bad; i++) {
         if (i == 1) p += 1;
         if (kGuard && p >= size) {
@@ -884,6 +890,11 @@ __device__ __forceinline__ int learn_shape_any(Tab tab, Src &ring, uint32_t at0,
         bad = !fast_varint(w, used, v);
         wide = wide || used > 4;
         uint32_t bytes = used >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * used));
+        // written the shortest way?  (the length and the two deltas are the head's: see walk_streamed)
+        if (kMinimal && i > 2) {
+            uint32_t z = ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
+            minimal = minimal && used == (38 - (uint32_t)__clz(z | 1u)) / 7;
+        }
         if (i < 3) {  // the head: scalars
             if (i == 0) {
                 n_len = used;
@@ -946,13 +957,13 @@ __device__ __forceinline__ int learn_shape_any(Tab tab, Src &ring, uint32_t at0,
     else if (bad || p != size) st = kWalkExact;
     out[0] = u32x4{(noted + 3) & ~3u, n_len | (wts << 8) | (wod << 16), (uint32_t)length, lenpat};
     out[1] = u32x4{o_key, o_val, (uint32_t)klen, (uint32_t)vlen};
-    out[2] = u32x4{hc, (uint32_t)st, size, 0};
+    out[2] = u32x4{hc, (uint32_t)st, size, minimal ? 1u : 0u};
     return st;
 }
 
 template <int kRows>
 __device__ __forceinline__ void learn_shape(lds_u128 *tab, RingView<kRows> ring, uint32_t at0, uint32_t size) {
-    learn_shape_any<false>(tab, ring, at0, size);
+    learn_shape_any<false, kRows != 8>(tab, ring, at0, size);  // (the kernel of small batches does not ask how the varints are written)
 }
 
 // A batch's record data in global memory as a source of learn_shape_any.
@@ -984,7 +995,7 @@ __device__ inline void guess_shape(const uint8_t *blob, const uint64_t *batch_of
                 uint32_t used;
                 int32_t length;
                 if (fast_varint(src.read64(0), used, length) && length >= 0 && (uint64_t)used + (uint32_t)length <= data_len)
-                    st = learn_shape_any<true>(tab, src, 0, used + (uint32_t)length);
+                    st = learn_shape_any<true, true>(tab, src, 0, used + (uint32_t)length);
             }
         }
     }
@@ -1007,7 +1018,8 @@ template <int kRows, bool kFold>
 __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c, uint32_t rec_base, HeaderSlots &slots,
                                              BatchStream<kRows, kFold> &stream, lds_u128 *tab, int lane,
                                              uint32_t *k_out, uint32_t *pos_out, bool seg = false,
-                                             uint32_t pos_end = 0xffffffffu, bool guessed = false) {
+                                             uint32_t pos_end = 0xffffffffu, bool guessed = false,
+                                             bool *minimal_out = nullptr) {
     uint32_t count = uni(c.record_count[b]);
     uint64_t rbase = rec_base;
     uint32_t data_len = uni(c.data_len[b]);
@@ -1020,6 +1032,12 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     shape.n_checks = 0;
     shape.size = 0;
     shape.hc = 0;
+    // Whether the walk's records are all written the shortest way, for the size the encoder
+    // can then take on trust: kept track of by the kernel of large batches only (the
+    // twelve-row ring).  In the kernel of small batches, which is the one that is short of
+    // registers, it costs the walk 4 % and saves the encoder a read of a hundred records.
+    constexpr bool kSized = kRows != 8;
+    bool all_minimal = true;  // every shape so far has its lengths and counts written the shortest way
     // the shape whose table lies in `tab` (learn_shape_any has just left it there, or it is a guess)
     auto load_shape = [&]() -> int {
         const lds_u128 *in4 = htab + kShapeHdrs;
@@ -1039,6 +1057,8 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         shape.klen = (int32_t)uni(b4.z);
         shape.vlen = (int32_t)uni(b4.w);
         shape.hc = uni(c4.x);
+        shape.minimal = uni(c4.w) != 0;
+        if (kSized) all_minimal = all_minimal && shape.minimal && shape.len_minimal();
         return learnt;
     };
     // `tab` holds a shape already (guess_shape's, of a batch nearby): the walk starts
@@ -1089,6 +1109,9 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     // two deltas, whose values (and the attributes byte) the lane keeps for the
     // records that fit; the rest by the table's compares.
     // (they go straight into `late`: the round before was flushed before any test of this one)
+    // (kSized) A delta of several bytes whose last byte is zero (not written the shortest way)
+    // fits no shape: no client writes one, and the sequential walk takes the batch.  So the
+    // records of a walk that ends here are written the shortest way if their shapes are.
     auto fitting = [&](uint32_t at, uint32_t m) -> uint32_t {
         if (shape.n_checks == 0) return 0;
         uint32_t diff = 0;
@@ -1110,10 +1133,14 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             late.attributes = (uint32_t)r1 & 0xffu;
             bool ok = fast_varlong((uint32_t)(r1 >> 8), w_used, ts);  // a shape's timestamp delta has at most four bytes
             late.ts = (int32_t)ts;
-            diff |= (w_used ^ shape.wts) | (ok ? 0u : 1u);
+            diff |= w_used ^ shape.wts;
             uint32_t o_used;
-            (void)fast_varint((uint64_t)ring.read32(at + shape.n_len + 1 + shape.wts), o_used, late.od);  // (a fifth byte: another width)
+            uint32_t od_word = ring.read32(at + shape.n_len + 1 + shape.wts);
+            (void)fast_varint((uint64_t)od_word, o_used, late.od);  // (a fifth byte: another width)
             diff |= o_used ^ shape.wod;
+            if (kSized && shape.wts > 1) ok = ok && ((uint32_t)(r1 >> (8 * shape.wts)) & 0xffu) != 0;
+            if (kSized && shape.wod > 1) ok = ok && ((od_word >> (8 * (shape.wod - 1))) & 0xffu) != 0;
+            diff |= ok ? 0u : 1u;
         }
         uint64_t fits = __ballot((uint32_t)lane < m && diff == 0);
         return uni(~fits ? (uint32_t)__ffsll((long long)~fits) - 1 : 64);
@@ -1250,6 +1277,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                             shape.o_val += moved;
                             shape.size = S;
                             shape.lenpat = uni((uint32_t)len_bytes) & shape.lenmask();
+                            if (kSized) all_minimal = all_minimal && shape.len_minimal();
                             m = fitting(at, same_size);
                         }
                     }
@@ -1322,6 +1350,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     flush();
     *k_out = k;
     *pos_out = pos;
+    if (kSized && minimal_out) *minimal_out = all_minimal && st == kWalkDone;
     return st;
 }
 
@@ -1909,10 +1938,17 @@ __device__ __forceinline__ bool find_record_start(const RingView<kRows> &ring, u
 }
 
 // Whether the chunks of batch b, whose work items start at `first`, join up.
-__device__ __forceinline__ bool segments_join(const Work &w, uint32_t first, uint32_t chunks, uint32_t count, int lane) {
-    bool good = true;
+// *sized: where the last record ends plus one if every chunk found its records written
+// the shortest way (the top bit of a chunk's end), else zero.
+__device__ __forceinline__ bool segments_join(const Work &w, uint32_t first, uint32_t chunks, uint32_t count, int lane,
+                                              uint32_t *sized) {
+    bool good = true, minimal = true;
+    uint32_t end = 0;
     for (uint32_t j = (uint32_t)lane; j < chunks; j += kWave) {
         u32x4 mine = *reinterpret_cast<const u32x4 *>(w.seg_info + 4 * (uint64_t)(first + j));
+        minimal = minimal && (mine.z >> 31);
+        mine.z &= 0x7fffffffu;
+        if (mine.w == count && mine.z > end) end = mine.z;
         good = good && mine.w != kSegFailed;
         if (j == 0) good = good && mine.x == 0 && mine.y == 0;
         if (j + 1 < chunks) {
@@ -1927,6 +1963,11 @@ __device__ __forceinline__ bool segments_join(const Work &w, uint32_t first, uin
             good = good && (mine.w == kSegNone || mine.w == count);
         }
     }
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t other = __shfl_xor(end, d, 64);
+        end = other > end ? other : end;
+    }
+    *sized = __all(minimal) ? end + 1 : 0u;
     return __all(good);
 }
 
@@ -2052,11 +2093,12 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     // here like any other, but for the CRC.
     bool in_chunks = !seg && (flags & kFlagChunks);
     bool joined_up = false;
+    uint32_t sized = 0;
     if (in_chunks && phase != kPhaseBeside) {
         uint32_t first_item = chunk_first(w, b, prefixed != 0, lane);
         uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, chunks, w.partial + first_item, t, lane);
         if (lane == 0) c.crc_computed[b] = v;
-        joined_up = (flags & kFlagSeg) && status == NISSHI_OK && segments_join(w, first_item, chunks, count, lane);
+        joined_up = (flags & kFlagSeg) && status == NISSHI_OK && segments_join(w, first_item, chunks, count, lane, &sized);
 #ifdef NISSHI_DIAG_JOINS  // diagnostic builds only: batches whose chunks did not join up, counted as sequential walks
         if ((flags & kFlagSeg) && !joined_up && lane == 0) {
             atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
@@ -2116,7 +2158,10 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
             return;
         }
         if (joined_up) {
-            if (lane == 0) c.hdr_count[b] = expect;
+            if (lane == 0) {
+                c.hdr_count[b] = expect;
+                if (c.enc_len != nullptr) c.enc_len[b] = sized;
+            }
             return;
         }
     }
@@ -2158,11 +2203,12 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     }
     uint32_t k = k0, pos = pos0;
     bool joined = false;  // seg: the chunk's records are decoded, as far as the chunk can tell
+    bool minimal = none;  // the unit's records are all written the shortest way (none are)
     if (do_walk) {
         HeaderSlots slots;
         slots.init(hdr_first, hdr_slots, hdr_cap);
         lds_order();
-        int st = walk_streamed(b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane, &k, &pos, seg, pos_end, guessed);
+        int st = walk_streamed(b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane, &k, &pos, seg, pos_end, guessed, &minimal);
         if (st == kWalkChain) st = walk_chain(blob, b, c, rec_base, slots, stream, lane, &k, &pos, seg, pos_end);
 #ifdef NISSHI_PHASES
         tl[3] = __builtin_readcyclecounter();
@@ -2173,6 +2219,8 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
             exact = true;
         } else if (lane == 0) {
             c.hdr_count[b] = slots.count;
+            // every record written the shortest way: they encode to the bytes they came from
+            if (kRows != 8 && minimal && k == count && !slots.over && !slots.full && c.enc_len != nullptr) c.enc_len[b] = pos + 1;
             if (uni((uint32_t)c.status[b]) != NISSHI_OK) {  // the columns ended inside the batch
                 atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 2), 1ull);
             } else if (slots.over) {
@@ -2207,7 +2255,7 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         if (lane == 0) {
             w.partial[mine] = r;
             *reinterpret_cast<u32x4 *>(w.seg_info + 4 * (uint64_t)mine) =
-                u32x4{pos0, k0, pos, joined ? k : none ? kSegNone : kSegFailed};
+                u32x4{pos0, k0, pos | (minimal ? 0x80000000u : 0u), joined ? k : none ? kSegNone : kSegFailed};
         }
     } else if (!in_chunks) {
         uint32_t v = stream.finish(t);
@@ -2323,10 +2371,29 @@ __device__ __forceinline__ void fused_body(const uint8_t *blob, const uint64_t *
 #endif
 }
 
+// The columns as a kernel argument without their last pointer, enc_len, which goes
+// behind the other arguments: a kernel that does not use it (the one of small
+// batches) then has the arguments it had without it.  That kernel holds its
+// arguments in scalar registers and is short of them: the pointer in their midst
+// had it load sixteen registers more at a time and move others out of the way.
+struct ColumnsArg {
+    uint64_t words[offsetof(nisshi_columns, enc_len) / 8];
+    ColumnsArg(const nisshi_columns &c) { __builtin_memcpy(words, &c, sizeof words); }
+    __device__ __forceinline__ nisshi_columns with(uint32_t *enc_len) const {
+        nisshi_columns c;
+        __builtin_memcpy(&c, words, sizeof words);
+        c.enc_len = enc_len;
+        return c;
+    }
+};
+static_assert(offsetof(nisshi_columns, enc_len) + 8 == sizeof(nisshi_columns), "enc_len is the last of the columns");
+
 template <int kRows, int kWaves, int kPack, bool kBeside>
 __global__ __launch_bounds__(64 * kPack) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves))) void decode_fused_kernel(
-    const uint8_t *blob, const uint64_t *batch_off, uint32_t n, nisshi_columns c, Work w, uint64_t rec_cap, uint64_t hdr_cap,
-    const CrcTables *t, uint32_t prefixed, const uint64_t *before, uint32_t big_from, uint32_t chunk_groups) {
+    const uint8_t *blob, const uint64_t *batch_off, uint32_t n, ColumnsArg cols, Work w, uint64_t rec_cap, uint64_t hdr_cap,
+    const CrcTables *t, uint32_t prefixed, const uint64_t *before, uint32_t big_from, uint32_t chunk_groups,
+    uint32_t *enc_len) {
+    nisshi_columns c = cols.with(kRows != 8 ? enc_len : nullptr);
     fused_body<kRows, kPack, kBeside ? kPhaseBeside : kPhaseAll>(blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before,
                                                                   big_from, chunk_groups);
 }

@@ -16,8 +16,10 @@ from . import columns as C
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnisshi_hip.so")
 
+ABI_VERSION = 2     # NISSHI_HIP_ABI_VERSION of the header these bindings follow
+
 EXPORTS = [
-    "nisshi_hip_ctx_create", "nisshi_hip_ctx_destroy", "nisshi_hip_status_str",
+    "nisshi_hip_abi_version", "nisshi_hip_ctx_create", "nisshi_hip_ctx_destroy", "nisshi_hip_status_str",
     "nisshi_hip_last_error", "nisshi_frame_split", "nisshi_records_prefix_decode",
     "nisshi_records_prefix_encode", "nisshi_records_fields_split", "nisshi_hip_count_dev", "nisshi_hip_decode_dev",
     "nisshi_hip_decode_dev_static",
@@ -111,6 +113,9 @@ def load() -> ctypes.CDLL:
         pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    if ABI_VERSION is not None and (not hasattr(lib, "nisshi_hip_abi_version") or lib.nisshi_hip_abi_version() != ABI_VERSION):
+        raise RuntimeError(f"{LIB_PATH} was built from another nisshi_hip.h than these bindings (rebuild: "
+                           "python -m tansu_amd.build)")
     lib.nisshi_hip_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
     lib.nisshi_hip_ctx_destroy.argtypes = [vp]
     lib.nisshi_hip_ctx_destroy.restype = None
@@ -234,6 +239,7 @@ class DeviceColumns:
             self.t[name] = torch.empty((n, words) if words > 1 else n, dtype=_torch_dtype(dt),
                                        device=device)
             setattr(self.c, name, self.t[name].data_ptr())
+        self.t["enc_len"].zero_()   # (nothing is known of the sizes of batches that no decode has filled in)
 
     def field(self, name: str):
         """The device tensor (a strided view, for grouped fields) of one field."""
@@ -248,7 +254,7 @@ class DeviceColumns:
         import torch
         self = cls(len(cols["status"]), len(cols["length"]), len(cols["hkey_off"]), device)
         for name, arr in C.pack(cols).items():
-            n = len(cols[{"rkey": "length", "rval": "length", "hdr": "hkey_off"}.get(name, name)])
+            n = len(cols[{"rkey": "length", "rval": "length", "hdr": "hkey_off", "enc_len": "status"}.get(name, name)])
             if n:
                 signed = np.ascontiguousarray(arr[:n]).view(np.dtype(f"i{arr.dtype.itemsize}"))
                 self.t[name][:n].copy_(torch.from_numpy(signed.copy()))

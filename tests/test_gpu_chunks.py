@@ -138,6 +138,10 @@ def test_few_and_many_batches_give_the_same_columns(codec):
     header_level = {f for _, fields in C.HEADER_GROUPS for f in fields}
     for name in g:
         n = totals.n_headers if name in header_level else len(g[name])
+        if name == "enc_len":   # which walk took a batch decides whether its size was noted, not what it is
+            both = (g[name] != 0) & (g2[name] != 0)
+            assert both.any() and (g[name][both] == g2[name][both]).all()
+            continue
         assert (g[name][:n] == g2[name][:n]).all(), name
     assert totals.n_records == totals2.n_records == nr
     assert totals.n_headers == totals2.n_headers == nh

@@ -15,6 +15,7 @@ from tansu_amd import hip, shard  # noqa: E402
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 enc = "--enc" in sys.argv
 hip.LIB_PATH = os.path.abspath(args[0])
+hip.ABI_VERSION = None      # (older builds, which end their columns a field earlier, ignore the last one)
 import torch  # noqa: E402
 
 codec = hip.Codec(0)

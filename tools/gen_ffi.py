@@ -46,6 +46,8 @@ def prototypes():
         params = []
         for a in args.split(","):
             a = " ".join(a.split())
+            if a == "void":     # (no parameters)
+                continue
             m = re.match(r"(.*?)(\w+)$", a)
             params.append((m.group(2), rust_type(m.group(1))))
         out.append((name, rust_type(ret), params))
