@@ -1,5 +1,10 @@
+#!/bin/bash
+# usage (on the GPU box, from the repository root): bash tools/profile_all.sh <round tag, e.g. r03>
+# tools/profile_round.sh over every workload; afterwards, where the repository is kept:
+# python tools/collect_profiles.py <round tag>
 set -e
-for w in c2 c1 c2v c3 c4 c5; do
-  timeout -k 10 1000 bash tools/profile_round.sh r02b_$w $w > gpurun_out/prof_r02b_$w.log 2>&1 || { echo "profile $w failed"; tail -5 gpurun_out/prof_r02b_$w.log; exit 1; }
+tag=${1:-r03}
+for w in c1 c2 c2v c3 c4 c5; do
+  timeout -k 10 1000 bash tools/profile_round.sh ${tag}_$w $w > gpurun_out/prof_${tag}_$w.log 2>&1 || { echo "profile $w failed"; tail -5 gpurun_out/prof_${tag}_$w.log; exit 1; }
   echo "$w done"
 done
