@@ -1167,7 +1167,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     constexpr uint32_t kChainBelow = 8;
     uint32_t strikes = 0;
 #ifdef NISSHI_PHASES
-    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = __builtin_readcyclecounter();
 #define PHASE(i) { uint64_t now_ = __builtin_readcyclecounter(); ph[i] += now_ - tmark; tmark = now_; }
 #else
@@ -1211,12 +1211,14 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         uint32_t start = pos + (uint32_t)lane * S;
         uint32_t at = start + bias;
         uint32_t m = 0;
+        bool deferred = false;  // the round only found a new size, whose rows are not in the ring yet
         // The usual round: the records have the size of the shape in hand and lie
         // inside the data, so testing them against the shape finds them; no
         // separate look at their lengths is needed (the shape holds the bytes of
         // the length).
         if (shape.n_checks && shape.size == S && (uint64_t)pos + (uint64_t)lanes * S <= data_len)
             m = fitting(at, lanes);
+        PHASE(8)
         if (m == 0) {
             // At most twice: when lane 0 is a record of another size and the ring
             // already holds what a round of that size reads, the round is looked for
@@ -1247,9 +1249,12 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                     S = uni(size);  // lane 0 is a record, of another size: guess again with that
                     cap = reach(S);
                     again = attempt == 0 && S <= kReach && window(pos, S, cap, count - k) <= stream.next_row;
+                    if (kSized) deferred = !again;  // (the kernel of small batches has no register for it)
                 } else {
                     // ---- which of them have the shape in hand; learn the first one's if it has not
+                    PHASE(9)
                     m = fitting(at, same_size);
+                    PHASE(10)
                     if (m == 0 && shape.n_checks && uni(used) <= 4) {
                         // The record at `pos` may differ from the shape only in its head: deltas a
                         // byte wider (or narrower) and a length that grew by as much.  Then the rest
@@ -1281,6 +1286,7 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
                             m = fitting(at, same_size);
                         }
                     }
+                    PHASE(11)
                     if (m == 0) {
                         if (lane == 0) learn_shape(tab, ring, pos + bias, S);
                         lds_order();
@@ -1300,7 +1306,8 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
             uint64_t inside = __ballot((uint32_t)lane < m && start < pos_end);
             m = (uint32_t)__builtin_popcountll(inside);
         }
-        strikes = m < kChainBelow && lanes >= 2 * kChainBelow ? strikes + 1 : 0;
+        // (a round that looked for no records yet says nothing about them)
+        if (!deferred) strikes = m < kChainBelow && lanes >= 2 * kChainBelow ? strikes + 1 : 0;
         if (strikes >= 2) {
             st = kWalkChain;
             __builtin_amdgcn_s_waitcnt(0x0F70);  // as at the end of the pass
@@ -1343,13 +1350,18 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
     }
 #ifdef NISSHI_PHASES
     if (lane == 0 && (b % 1024) == 7)
-        printf("b=%u other=%lu pull=%lu load=%lu flush=%lu spec=%lu fit=%lu emit=%lu take=%lu\n", b, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+        printf("b=%u other=%lu pull=%lu load=%lu flush=%lu spec=%lu fit=%lu emit=%lu take=%lu | fit1=%lu len=%lu fit2=%lu rebase=%lu\n", b, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], ph[10], ph[11]);
 #endif
     // a shape that failed to be learnt has overwritten nothing the flush needs:
     // learning follows the flush of its round
     flush();
     *k_out = k;
     *pos_out = pos;
+#ifdef NISSHI_DIAG_MIN
+    if (lane == 0 && kSized && (!all_minimal || st != kWalkDone))
+        printf("walk b=%u seg=%d k=%u pos=%u st=%d all=%d shape.min=%d len_min=%d n_len=%u length=%d wts=%u wod=%u\n", b, (int)seg, k, pos, st,
+               (int)all_minimal, (int)shape.minimal, (int)shape.len_minimal(), shape.n_len, shape.length, shape.wts, shape.wod);
+#endif
     if (kSized && minimal_out) *minimal_out = all_minimal && st == kWalkDone;
     return st;
 }

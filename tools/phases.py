@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from tansu_amd import hip, shard
 hip.LIB_PATH = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "scratch", "libs", "phases.so"))
+hip.ABI_VERSION = None
 import torch
 codec = hip.Codec(0)
 scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
