@@ -1,0 +1,34 @@
+"""Gather what tools/evidence.sh left under gpurun_out/ into tracked files of profiles/:
+<tag>_default_bench.json, <tag>_launcher_pool.json, <tag>_operators.json, <tag>_inflate.json.
+usage: python tools/collect_evidence.py <round tag>"""
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from tansu_amd.build import source_hash
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+
+
+def last_json(name):
+    text = open(os.path.join(root, "gpurun_out", f"{tag}_{name}.json")).read().strip()
+    try:
+        return json.loads(text)
+    except ValueError:
+        for line in reversed(text.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        raise
+
+
+def put(name, value):
+    value = dict(value, csrc_sha=source_hash())
+    json.dump(value, open(os.path.join(root, "profiles", f"{tag}_{name}.json"), "w"), indent=1)
+
+
+put("default_bench", last_json("default_bench"))
+put("launcher_pool", {"note": "python bench.py --gpus 2 (two ranks on the box's one GPU), --pool 1, --pool 2 (two contexts of the one GPU)",
+                      "gpus2": last_json("gpus2"), "pool1": last_json("pool1"), "pool2": last_json("pool2")})
+put("operators", {"note": "HIP-event kernel times (ms) at the C2 size: tools/storage_time.py (decode, produce rows, combine in groups of 8, encode) "
+                          "and tools/ops_time.py (fetch, encode of its batches, compaction)",
+                  "storage_time": last_json("storage_time"), "ops_time": last_json("ops_time")})
+put("inflate", {c: last_json(f"inflate_{c}") for c in ("snappy", "lz4", "gzip", "zstd")})
+print("collected", tag, source_hash())
