@@ -1362,7 +1362,8 @@ __device__ __forceinline__ int walk_streamed(uint32_t b, const nisshi_columns &c
         printf("walk b=%u seg=%d k=%u pos=%u st=%d all=%d shape.min=%d len_min=%d n_len=%u length=%d wts=%u wod=%u\n", b, (int)seg, k, pos, st,
                (int)all_minimal, (int)shape.minimal, (int)shape.len_minimal(), shape.n_len, shape.length, shape.wts, shape.wod);
 #endif
-    if (kSized && minimal_out) *minimal_out = all_minimal && st == kWalkDone;
+    // (a walk handed on to the chained walk: that one goes on keeping track)
+    if (kSized && minimal_out) *minimal_out = all_minimal && (st == kWalkDone || st == kWalkChain);
     return st;
 }
 
@@ -1548,8 +1549,11 @@ template <int kRows, bool kFold>
 __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const nisshi_columns &c, uint32_t rec_base,
                                           HeaderSlots &slots, BatchStream<kRows, kFold> &stream, int lane,
                                           uint32_t *k_io, uint32_t *pos_io, bool seg = false,
-                                          uint32_t pos_end = 0xffffffffu) {
+                                          uint32_t pos_end = 0xffffffffu, bool *minimal_io = nullptr) {
     typedef RingView<kRows> Ring;
+    // (as in walk_streamed: whether every varint is written the shortest way, in the kernel of large batches)
+    constexpr bool kSized = kRows != 8;
+    bool all_minimal = true;
     uint32_t count = uni(c.record_count[b]);
     uint64_t rbase = rec_base;
     uint32_t data_len = uni(c.data_len[b]);
@@ -1666,6 +1670,7 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
             // between here and the next record still pass through the stream for the CRC
             __builtin_amdgcn_s_waitcnt(0x0F70);
             uint32_t end = 0;
+            if (kSized) all_minimal = false;  // (its varints are not looked at)
             int outcome = large_record(blob, b, c, rbase + k, pos, data_len, slots, lane, &end);
             if (outcome == 1) {
                 st = kWalkExact;
@@ -1687,7 +1692,11 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
         uint32_t ro0 = RingCfg<kRows>::wrap(start + bias);
         RecordFields f;
         uint32_t used, q_used;
-        bool ok = fast_varint(ring.read40(ro0), used, f.length) && live;  // known to be good in live lanes
+        uint32_t slack = 1;  // zero: one of the record's varints is longer than its value needs
+        auto varint = [&](uint64_t w, uint32_t &n_used, int32_t &v) -> bool {
+            return kSized ? fast_varint_noting(w, n_used, v, slack) : fast_varint(w, n_used, v);
+        };
+        bool ok = varint(ring.read40(ro0), used, f.length) && live;  // known to be good in live lanes
         uint32_t end = start + used + (uint32_t)f.length;
         uint32_t o = used;  // offset in the record
         auto at = [&](uint32_t off) { return Ring::wrap1(ro0 + off); };
@@ -1697,22 +1706,27 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
             o += 1;
             bool quick = fast_varlong((uint32_t)(w0 >> 8), q_used, f.timestamp_delta);
             if (!quick) ok = ring_varlong(ring, at(o), q_used, f.timestamp_delta) && ok;
+            // (a delta of five bytes and more is not looked at: taken as not the shortest)
+            if (kSized) {
+                uint32_t last = quick ? (((uint32_t)(w0 >> 8) >> (8 * (q_used - 1))) & 0xffu) | ((q_used - 2u) >> 31) : 0u;
+                slack = last < slack ? last : slack;
+            }
             o += q_used;
         }
         uint32_t body = end - start;  // the record's bytes, its length varint included
-        ok = fast_varint(ring.read40(at(o)), q_used, f.offset_delta) && ok;
+        ok = varint(ring.read40(at(o)), q_used, f.offset_delta) && ok;
         o += q_used;
-        ok = fast_varint(ring.read40(at(o)), q_used, f.key_len) && ok;
+        ok = varint(ring.read40(at(o)), q_used, f.key_len) && ok;
         o += q_used;
         f.key_off = start + o;
         ok = ok && f.key_len >= -1 && o <= body && (uint32_t)(f.key_len < 0 ? 0 : f.key_len) <= body - o;
         o += ok && f.key_len > 0 ? (uint32_t)f.key_len : 0u;
-        ok = fast_varint(ring.read40(at(o)), q_used, f.val_len) && ok;
+        ok = varint(ring.read40(at(o)), q_used, f.val_len) && ok;
         o += ok ? q_used : 0u;
         f.val_off = start + o;
         ok = ok && f.val_len >= -1 && o <= body && (uint32_t)(f.val_len < 0 ? 0 : f.val_len) <= body - o;
         o += ok && f.val_len > 0 ? (uint32_t)f.val_len : 0u;
-        ok = fast_varint(ring.read40(at(o)), q_used, f.hdr_count) && ok;
+        ok = varint(ring.read40(at(o)), q_used, f.hdr_count) && ok;
         o += ok ? q_used : 0u;
         // a header is at least two bytes: a count the record cannot hold is an error
         ok = ok && f.hdr_count >= 0 && o <= body && (uint32_t)f.hdr_count <= (body - o) / 2;
@@ -1739,18 +1753,22 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
                     bool mine = j < hc && ok;
                     int32_t kl = 0, vl = 0;
                     uint32_t ko, vo, n1, n2;
-                    bool good = fast_varint(ring.read40(at(mine ? o : 0u)), n1, kl);
+                    uint32_t slack_h = 1;
+                    bool good = kSized ? fast_varint_noting(ring.read40(at(mine ? o : 0u)), n1, kl, slack_h)
+                                       : fast_varint(ring.read40(at(mine ? o : 0u)), n1, kl);
                     uint32_t o1 = o + n1;
                     ko = start + o1;
                     good = good && kl >= -1 && o1 <= body && (uint32_t)(kl < 0 ? 0 : kl) <= body - o1;
                     o1 += good && kl > 0 ? (uint32_t)kl : 0u;
-                    good = fast_varint(ring.read40(at(mine && good ? o1 : 0u)), n2, vl) && good;
+                    good = (kSized ? fast_varint_noting(ring.read40(at(mine && good ? o1 : 0u)), n2, vl, slack_h)
+                                   : fast_varint(ring.read40(at(mine && good ? o1 : 0u)), n2, vl)) && good;
                     o1 += n2;
                     vo = start + o1;
                     good = good && vl >= -1 && o1 <= body && (uint32_t)(vl < 0 ? 0 : vl) <= body - o1;
                     o1 += good && vl > 0 ? (uint32_t)vl : 0u;
                     if (mine) {
                         ok = good;
+                        slack = slack_h < slack ? slack_h : slack;
                         if (good) {
                             o = o1;
                             if (keep) store_header(c, slot + j, ko, kl, vo, vl);
@@ -1775,6 +1793,7 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
             break;
         }
         PHASE(5)
+        if (kSized) all_minimal = all_minimal && !__any(live && slack == 0);
         if (live) store_record(c, rbase + k, (uint32_t)lane, f, slot);
         k += n;
         pos = p;
@@ -1796,6 +1815,7 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
         printf("chain b=%u rounds=%u records=%u other=%lu pull=%lu hops=%lu tail=%lu fields=%lu headers=%lu store=%lu take=%lu\n", b,
                n_rounds, k - k_first, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
 #endif
+    if (kSized && minimal_io) *minimal_io = *minimal_io && all_minimal && st == kWalkDone;
     *k_io = k;
     *pos_io = pos;
     return st;
@@ -2221,7 +2241,7 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         slots.init(hdr_first, hdr_slots, hdr_cap);
         lds_order();
         int st = walk_streamed(b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane, &k, &pos, seg, pos_end, guessed, &minimal);
-        if (st == kWalkChain) st = walk_chain(blob, b, c, rec_base, slots, stream, lane, &k, &pos, seg, pos_end);
+        if (st == kWalkChain) st = walk_chain(blob, b, c, rec_base, slots, stream, lane, &k, &pos, seg, pos_end, &minimal);
 #ifdef NISSHI_PHASES
         tl[3] = __builtin_readcyclecounter();
 #endif

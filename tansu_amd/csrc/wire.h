@@ -74,6 +74,26 @@ __device__ __forceinline__ bool fast_varint(uint64_t w, uint32_t &used, int32_t 
     return stop != 0 || !(hi & 0x80u);
 }
 
+// fast_varint that also notes whether the varint was longer than its value needs (its last byte
+// carries no bits: what the encoder would write is shorter).  A fifth byte with only bits that
+// are dropped counts as such too.  `slack` ends up zero if any varint noted into it was: the
+// least, over them, of the last byte's bits, a varint of one byte counting as one.  (Kept in a
+// vector register on purpose: a bool a varint would be scalar instructions, of which the
+// chained walk has none to spare.)
+__device__ __forceinline__ bool fast_varint_noting(uint64_t w, uint32_t &used, int32_t &out, uint32_t &slack) {
+    uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    uint32_t stop = ~lo & 0x80808080u;
+    uint32_t idx = stop ? (uint32_t)__builtin_ctz(stop) >> 3 : 4u;
+    uint32_t v = (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) | ((lo >> 2) & 0x1fc000u) |
+                 ((lo >> 3) & 0xfe00000u) | (hi << 28);
+    v &= idx == 4 ? 0xffffffffu : 0xffffffffu >> (25 - 7 * idx);
+    uint32_t last = (v >> (7 * idx)) | ((idx - 1u) >> 31);
+    slack = last < slack ? last : slack;
+    used = idx + 1;
+    out = (int32_t)(v >> 1) ^ -(int32_t)(v & 1u);
+    return stop != 0 || !(hi & 0x80u);
+}
+
 // The same for LongVarInt::decode when it ends within four bytes (|value| < 2^27).
 __device__ __forceinline__ bool fast_varlong(uint32_t lo, uint32_t &used, int64_t &out) {
     uint32_t stop = ~lo & 0x80808080u;

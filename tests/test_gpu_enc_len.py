@@ -109,6 +109,39 @@ def test_small_batches_through_the_kernel_that_notes_sizes(wide_codec):
     assert got == want
 
 
+def test_records_of_changing_sizes_carry_their_size_too(codec):
+    """Records whose sizes change from one to the next are walked along their lengths (the chained walk),
+    which looks at how every varint is written as well; one padded varint in one record and the batch is sized
+    by the encoder again."""
+    blob, off, nr, nh = synth.make_var_batches(12, 1000, 31)
+    blob = bytearray(blob.tobytes())
+    st, c0, _, _ = oracle.decode_columns(bytes(blob), off, True)
+    # batch 5, record 700: its key length (16: one byte, 0x20) becomes 0xa0 0x00 -- two bytes for the same
+    # value -- and its length varint one more; what follows moves up a byte
+    at = int(off[5]) + 61 + int(c0["key_off"][5 * 1000 + 700]) - 1
+    assert blob[at] == 0x20
+    rec = at - 1 - 2 - 2 - 2      # (the record's start: length of two bytes, attributes, two deltas of two bytes)
+    length = (blob[rec] & 0x7f) | (blob[rec + 1] << 7)
+    assert blob[rec] & 0x80 and not blob[rec + 1] & 0x80 and length // 2 > 100
+    length += 2                   # (zigzag: the body is one byte longer)
+    patched = blob[:rec] + bytes([0x80 | (length & 0x7f), length >> 7]) + blob[rec + 2:at] + b"\xa0\x00" + blob[at + 1:]
+    head = bytearray(patched[int(off[5]):int(off[5]) + 61])
+    struct.pack_into(">i", head, 8, struct.unpack_from(">i", head, 8)[0] + 1)
+    patched[int(off[5]):int(off[5]) + 61] = head
+    off = off.copy()
+    off[6:] += 1
+    blob, cols, d_blob = decode(codec, bytes(patched), off)
+    n = len(off) - 1
+    assert (cols.t["status"].cpu().numpy()[:n] == C.OK).all()
+    c, want = checker_bytes(blob, off)
+    enc_len = cols.t["enc_len"].cpu().numpy().view(np.uint32)[:n]
+    expect = c["data_len"][:n] + 1
+    expect[5] = 0
+    assert (enc_len == expect).all()
+    got, _ = encode(codec, cols, n, d_blob, len(blob) + 64)
+    assert got == want and len(want) == len(blob) - 1
+
+
 def uv(n: int) -> bytes:
     """The zigzag varint of n, written the shortest way."""
     z = (n << 1) ^ (n >> 63)
