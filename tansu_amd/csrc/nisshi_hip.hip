@@ -1545,11 +1545,175 @@ __device__ __forceinline__ bool ring_varlong(const RingView<kRows> &ring, uint32
     return done;
 }
 
+// The record starts of one round of the chained walk found by sixteen chains of hops side by side
+// instead of one after the other.  One chain of hops is a chain of dependent LDS reads: 240 cycles a
+// record, 64 records a round, half of what a wave spends on such a batch.  Here the round's window is
+// cut into sixteen stretches; the first chain starts at `pos`, which is a record's start, and each of
+// the others at a *candidate* near the beginning of its stretch: the first byte position there that
+// looks like the head of a record (a length varint of two bytes that is not negative, and an
+// attributes byte of zero, found by four lanes that test 48 positions each, four at a time in a
+// register).  All chains hop in step, every lane its own (the four lanes of a chain the same one), a
+// chain noting the starts it passes in a list in LDS.  A chain ends when it lands exactly on the start
+// of a chain ahead of it: from there on that chain's hops are the very hops it would have made
+// itself.  A chain that passes a start without landing on it leaves that chain out (its candidate was
+// no record's start, or is not reached) and aims at the next.  The round's records are then the
+// lists of the chains that were landed on, one after the other from the first: the same starts the
+// single chain finds, by construction -- nothing of a chain is used unless hops from `pos` led to
+// where it started.  `scratch`: 544 bytes of LDS (the shape table, which the chained walk does not
+// use).  Leaves the number of records found (at most `want`), where the next one starts, and lane i's
+// start; false when the round is not worth it (a short window), nothing done.
+constexpr uint32_t kAbreast = 16, kAbreastCap = 15, kAbreastScan = 12;  // chains, starts a chain, dwords a lane scans
+template <int kRows>
+__device__ __forceinline__ bool chains_abreast(const RingView<kRows> &ring, lds_u32 *scratch, uint32_t bias, uint32_t pos,
+                                               uint32_t limit, uint32_t want, uint32_t mean, int lane, uint32_t &n_out,
+                                               uint32_t &p_out, uint32_t &my_start) {
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    constexpr uint32_t kRing = RingCfg<kRows>::kRingBytes;
+    constexpr uint32_t kScanBytes = kAbreastScan * 4, kQuad = 64 / kAbreast;
+    lds_u16 *list = (lds_u16 *)scratch;                 // [kAbreast][kAbreastCap + 1]: starts less `pos`, then the chain's end
+    lds_u16 *starts = list + kAbreast * (kAbreastCap + 1);  // [kAbreast]: where each chain starts, less `pos`
+    uint32_t span = limit - pos, expect = want * mean + mean;
+    span = expect < span ? expect : span;
+    uint32_t stride = span / kAbreast;
+    if (stride < kQuad * kScanBytes + 32) return false;
+    uint32_t c = (uint32_t)lane / kQuad, sub = (uint32_t)lane % kQuad;
+#ifdef NISSHI_PHASES
+    uint64_t t0 = __builtin_readcyclecounter();
+#endif
+    // ---- the candidates
+    uint32_t start = 0xffffffffu;  // the chain's start as a position in the record data
+    {
+        uint32_t q0 = ((pos + c * stride + bias) & ~15u) + sub * kScanBytes;  // in the stream's bytes: the ring's grid
+        const lds_u32 *rp = ring.ring + (RingCfg<kRows>::wrap(q0) >> 2);
+        uint32_t d[kAbreastScan + 1];
+#pragma unroll
+        for (uint32_t j = 0; j < kAbreastScan; j += 4) {
+            u32x4 v = *reinterpret_cast<const lds_u128 *>(rp + j);
+            d[j] = v.x, d[j + 1] = v.y, d[j + 2] = v.z, d[j + 3] = v.w;
+        }
+        d[kAbreastScan] = rp[kAbreastScan];
+        uint32_t first = 0xffffu;
+#pragma unroll
+        for (int j = (int)kAbreastScan - 1; j >= 0; j--) {
+            uint32_t w = d[j], nx = d[j + 1];
+            uint32_t b1 = __builtin_amdgcn_alignbit(nx, w, 8), b2 = __builtin_amdgcn_alignbit(nx, w, 16);
+            uint32_t nz = ((b2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | b2;  // bit 7 of a byte: the byte two on is not zero
+            // the byte continues, is even (no negative length), the next ends the varint, the one after is zero
+            uint32_t cand = w & ~(w << 7) & ~b1 & ~nz & 0x80808080u;
+            uint32_t at = (uint32_t)j * 4 + ((uint32_t)__builtin_ctz(cand | 0x80000000u) >> 3);
+            first = cand ? at : first;
+        }
+        uint32_t found = first != 0xffffu ? q0 + first - bias : 0xffffffffu;
+        uint32_t o = (uint32_t)__shfl_xor((int)found, 1, 64);
+        found = o < found ? o : found;
+        o = (uint32_t)__shfl_xor((int)found, 2, 64);
+        found = o < found ? o : found;
+        start = c == 0 ? pos : found;
+        if (c && start != 0xffffffffu && start <= pos) start = 0xffffffffu;  // (never at or before `pos`)
+        if (start != 0xffffffffu && start + 7 > limit) start = 0xffffffffu;
+    }
+    // which chains there are, a bit a chain
+    uint64_t quads = __ballot(start != 0xffffffffu) & 0x1111111111111111ull;
+    quads = (quads | (quads >> 3)) & 0x0303030303030303ull;
+    quads = (quads | (quads >> 6)) & 0x000f000f000f000full;
+    quads = (quads | (quads >> 12)) & 0x000000ff000000ffull;
+    uint32_t exist = (uint32_t)(quads | (quads >> 24)) & 0xffffu;
+    if (sub == 0) starts[c] = (uint16_t)(start - pos);
+    lds_order();
+    auto chain_after = [&](uint32_t t) -> uint32_t {  // the next chain there is after chain t; kAbreast: none
+        uint32_t ahead = exist & ~((2u << t) - 1u);
+        return ahead ? (uint32_t)__builtin_ctz(ahead) : kAbreast;
+    };
+#ifdef NISSHI_PHASES
+    uint64_t t1 = __builtin_readcyclecounter();
+    uint32_t steps_done = 0;
+#endif
+    // ---- the hops
+    bool alive = start != 0xffffffffu, landed = false;
+    uint32_t pc = alive ? start : pos, roc = RingCfg<kRows>::wrap(pc + bias), cnt = 0;
+    uint32_t tgt = chain_after(c);
+    uint32_t tpos = tgt < kAbreast ? pos + starts[tgt] : 0xffffffffu;
+#pragma unroll 1
+    for (uint32_t step = 0; step < kAbreastCap; step++) {
+        bool act = alive && !landed;
+        if (!__any(act)) break;
+#ifdef NISSHI_PHASES
+        steps_done++;
+#endif
+        uint32_t used;
+        int32_t len;
+        bool ok = fast_varint(ring.read40(roc), used, len) && len >= 0;
+        uint32_t size = used + (uint32_t)len;
+        bool take = act && ok && size <= limit - pc;
+        if (act && !take) alive = false;  // the chain stops here: no record, or one that ends beyond the round
+        if (take) {
+            list[c * (kAbreastCap + 1) + cnt] = (uint16_t)(pc - pos);
+            cnt++;
+            pc += size;
+            roc += size;
+            roc = roc >= kRing ? roc - kRing : roc;
+#pragma unroll 1
+            for (uint32_t t = 0; t < kAbreast && pc > tpos; t++) {  // passed a start without landing on it
+                tgt = chain_after(tgt);
+                tpos = tgt < kAbreast ? pos + starts[tgt] : 0xffffffffu;
+            }
+            landed = pc == tpos;
+            // (the last chain has nothing to land on: it ends where the round is expected to)
+            if (tgt >= kAbreast && pc >= pos + span) alive = false;
+        }
+    }
+    list[c * (kAbreastCap + 1) + cnt] = (uint16_t)(pc - pos);  // where the chain ended
+    lds_order();
+#ifdef NISSHI_PHASES
+    uint64_t t2 = __builtin_readcyclecounter();
+#endif
+    // ---- the chains that were landed on, in order.  What the sixteen chains ended with is read
+    // into scalar registers (sixteen reads of a lane at a fixed place), the path from the first chain
+    // is followed there, and every lane finds its chain by comparing its number with where the
+    // chains' records begin in the round.
+    uint32_t ended = cnt | (tgt << 8) | (landed ? 0x10000u : 0u);
+    uint32_t on_path = 1, off = 0, end_chain = 0, end_at = 0;
+    bool open = true;  // the round's end has not been found yet
+    uint32_t chain_of = 0, base_of = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kAbreast; j++) {
+        uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ended, (int)(j * kQuad));
+        bool mine = open && (on_path >> j & 1u);
+        uint32_t have = e & 0xffu, room = want - off;
+        uint32_t some = have < room ? have : room;
+        uint32_t from = mine ? off : 0xffffu;  // (a chain off the path begins nowhere)
+        chain_of = (uint32_t)lane >= from ? j : chain_of;
+        base_of = (uint32_t)lane >= from ? from : base_of;
+        if (mine) {
+            off += some;
+            end_chain = j, end_at = some;
+            bool goes_on = some == have && (e & 0x10000u) != 0;  // all of it taken, and it landed on a chain
+            open = goes_on;
+            if (goes_on) {
+                uint32_t nxt = (e >> 8) & 0xffu;
+                on_path |= 1u << nxt;
+                end_chain = nxt, end_at = 0;
+            }
+        }
+    }
+    uint32_t idx_of = (uint32_t)lane - base_of;
+    n_out = uni(off);
+    p_out = uni(pos + list[uni(end_chain) * (kAbreastCap + 1) + uni(end_at)]);
+    my_start = pos + list[chain_of * (kAbreastCap + 1) + idx_of];
+#ifdef NISSHI_PHASES
+    uint64_t t3 = __builtin_readcyclecounter();
+    if (lane == 0 && pos < 20000)
+        printf("abreast pos=%u scan=%lu hops=%lu steps=%u join=%lu exist=%x n=%u\n", pos, t1 - t0, t2 - t1, steps_done, t3 - t2, exist, n_out);
+#endif
+    return true;
+}
+
 template <int kRows, bool kFold>
 __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const nisshi_columns &c, uint32_t rec_base,
                                           HeaderSlots &slots, BatchStream<kRows, kFold> &stream, int lane,
                                           uint32_t *k_io, uint32_t *pos_io, bool seg = false,
-                                          uint32_t pos_end = 0xffffffffu, bool *minimal_io = nullptr) {
+                                          uint32_t pos_end = 0xffffffffu, bool *minimal_io = nullptr,
+                                          lds_u32 *scratch = nullptr) {
     typedef RingView<kRows> Ring;
     // (as in walk_streamed: whether every varint is written the shortest way, in the kernel of large batches)
     constexpr bool kSized = kRows != 8;
@@ -1564,6 +1728,13 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
     Ring ring{stream.ring};
     uint32_t k = uni(*k_io), pos = uni(*pos_io);
     int st = kWalkDone;
+    // Rounds of records of 64 bytes and more on average find their starts by chains of hops side
+    // by side (chains_abreast), in the kernel of large batches, which has the registers for it.
+    uint32_t mean = count ? data_len / count : 0;
+    bool abreast = kRows == 12 && scratch != nullptr && mean >= 64;
+#ifdef NISSHI_NO_ABREAST
+    abreast = false;
+#endif
 #ifdef NISSHI_PHASES
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = __builtin_readcyclecounter();
@@ -1592,7 +1763,23 @@ __device__ __forceinline__ int walk_chain(const uint8_t *blob, uint32_t b, const
         uint32_t limit = data_len - pos < kReach ? data_len : pos + kReach;
         uint32_t p = pos, n = 0, ro = RingCfg<kRows>::wrap(pos + bias);
         uint32_t my_start = 0;
-        {
+        bool found_abreast = false;
+        if (abreast && want >= 32) {
+            const lds_u32 *w = ring.ring + (ro >> 2);
+            uint32_t d0 = uni(w[0]), d1 = uni(w[1]);
+            uint32_t lo = (uint32_t)((((uint64_t)d1 << 32) | d0) >> (8 * (ro & 3)));
+            uint32_t n2 = 0, p2 = pos, s2 = 0;
+            // (the candidates are looked for by the form of a length of two bytes)
+            if ((lo & 0x8080u) == 0x80u && chains_abreast<kRows>(ring, scratch, bias, pos, limit, want, mean, lane, n2, p2, s2)) {
+                found_abreast = true;
+                n = n2;
+                p = p2;
+                my_start = s2;
+                ro = RingCfg<kRows>::wrap(p + bias);
+                if (n < 24) abreast = false;  // not this batch's kind of records: one chain from here on
+            }
+        }
+        if (!found_abreast) {
             // lengths of one byte and of two, each by a loop of its own (hop_loop); a
             // change of form, or anything else that stops a loop, is looked at here
             uint32_t my_left = 0;  // the lane's start as the distance to `limit`
@@ -2241,7 +2428,8 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         slots.init(hdr_first, hdr_slots, hdr_cap);
         lds_order();
         int st = walk_streamed(b, c, rec_base, slots, stream, (lds_u128 *)shape_tab, lane, &k, &pos, seg, pos_end, guessed, &minimal);
-        if (st == kWalkChain) st = walk_chain(blob, b, c, rec_base, slots, stream, lane, &k, &pos, seg, pos_end, &minimal);
+        if (st == kWalkChain)
+            st = walk_chain(blob, b, c, rec_base, slots, stream, lane, &k, &pos, seg, pos_end, &minimal, (lds_u32 *)shape_tab);
 #ifdef NISSHI_PHASES
         tl[3] = __builtin_readcyclecounter();
 #endif

@@ -14,7 +14,8 @@ import numpy as np
 
 from . import columns as C
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnisshi_hip.so")
+# (NISSHI_HIP_LIB in the environment: another build of the library, for the tools that compare builds)
+LIB_PATH = os.environ.get("NISSHI_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnisshi_hip.so")
 
 ABI_VERSION = 2     # NISSHI_HIP_ABI_VERSION of the header these bindings follow
 

@@ -195,6 +195,45 @@ def test_records_of_changing_sizes_vs_oracle(codec):
     assert out[:t.out_bytes].cpu().numpy().tobytes() == blob.tobytes()
 
 
+def test_changing_sizes_with_payloads_that_look_like_record_heads():
+    """The chained walk of large batches looks for places where a record may start (a length of two bytes
+    that is not negative, then a zero byte) and lets hops from the round's first record decide which of them
+    are: payloads made of exactly such bytes, records of a byte's length among them, records with nonzero
+    attributes (which no candidate is found for), and a batch of nothing but short records."""
+    import os
+    os.environ["NISSHI_WIDE_RING_FROM"] = "0"      # (the kernel of large batches, whatever the batches' size)
+    try:
+        codec = hip.Codec(0)
+    finally:
+        del os.environ["NISSHI_WIDE_RING_FROM"]
+    rng = np.random.default_rng(41)
+    head = bytes([0x90, 0x01, 0x00])               # as a record's first bytes: length 72, attributes 0
+    batches = []
+    for kind in range(5):
+        records = []
+        for i in range(1100):
+            n = int(rng.integers(60, 200))
+            value = (head * 80)[int(rng.integers(0, 3)):][:n]
+            key = None if i % 7 else (head * 4)[:int(rng.integers(0, 12))]
+            headers = [C.Header(b"h", (head * 9)[:int(rng.integers(0, 25))])] if i % 3 == 0 else []
+            attributes = 0
+            if kind == 1 and i % 50 == 49:
+                value = value[:int(rng.integers(1, 30))]          # a record under 64 bytes: a length of one byte
+            if kind == 2 and i % 40 == 11:
+                attributes = 0x20
+            if kind == 3:
+                value = value[:20]                                # all short
+            if kind == 4 and i % 200 == 150:
+                value = bytes(rng.integers(0, 256, 9000, dtype=np.uint8))   # a length of three bytes
+            records.append(C.Record(0, attributes, i * 3, i, key, value, headers))
+        batches.append(build_batch(dict(base_offset=kind * 5000, last_offset_delta=len(records) - 1), records))
+    blob = b"".join(batches)
+    off = offsets_of(batches)
+    g, c, totals, cols, d_blob, d_off = check_against_oracle(codec, blob, off)
+    assert (totals.n_failed, totals.n_records) == (0, 5 * 1100)
+    codec.close()
+
+
 def test_changing_sizes_with_a_wrong_length_and_a_large_record(codec):
     """The chained walk's ways out: a record whose length disagrees with its fields
     deep inside a batch (the sequential walk takes over and accepts it, as the
