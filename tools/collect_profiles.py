@@ -19,7 +19,8 @@ for workload in workloads:
     src = os.path.join(root, "gpurun_out", f"prof_{tag}_{workload}")
     name = f"{tag}_{workload}"
     summary = json.load(open(os.path.join(src, "summary.json")))
-    stats = glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)[0]
+    # (gpurun merges a run's files into what earlier runs left: the newest is this run's)
+    stats = max(glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
     copies = {f"{name}_kernel_stats.csv": stats, f"{name}_summary.json": os.path.join(src, "summary.json"),
               f"{name}_bench_under_rocprof.json": os.path.join(src, "trace_bench.json")}
     for to, frm in copies.items():
