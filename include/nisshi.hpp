@@ -578,15 +578,21 @@ inline Result<deflated::Frame> deflate(Codec &codec, const inflated::Frame &fram
     HostColumns cols(nb, nr, nh);
     std::vector<uint8_t> payload;
     std::vector<uint64_t> src_off(nb ? nb : 1, 0);
+    // into_record_data (deflated.rs:341-386) compresses a batch's record data with the batch's codec: the
+    // batches are encoded uncompressed first and those with a codec compressed behind that, in one call more
+    std::vector<uint8_t> want(nb ? nb : 1, 0);
+    bool any_codec = false;
     size_t r = 0, h = 0;
     for (size_t b = 0; b < nb; b++) {
         const inflated::Batch &ib = frame.batches[b];
+        want[b] = uint8_t(ib.attributes & 7);
+        any_codec = any_codec || want[b] != 0;
         cols.base_offset[b] = ib.base_offset;
         cols.batch_length[b] = ib.batch_length;
         cols.partition_leader_epoch[b] = ib.partition_leader_epoch;
         cols.magic[b] = ib.magic;
         cols.crc[b] = ib.crc;
-        cols.attributes[b] = ib.attributes;
+        cols.attributes[b] = int16_t(ib.attributes & ~7);
         cols.last_offset_delta[b] = ib.last_offset_delta;
         cols.base_timestamp[b] = ib.base_timestamp;
         cols.max_timestamp[b] = ib.max_timestamp;
@@ -633,6 +639,22 @@ inline Result<deflated::Frame> deflate(Codec &codec, const inflated::Frame &fram
     int st = nisshi_hip_encode(codec.ctx(), &c, uint32_t(nb), nr, nh, payload.data(), payload.size(),
                                src_off.data(), out.data(), out_cap, out_off.data(), &totals);
     if (st) return Error::from_status(st);
+    if (any_codec) {
+        // LZ4 on the device (nisshi_hip_deflate); gzip and zstd, which the reference compresses too, are not
+        // produced there, and Snappy the reference refuses itself (Error::UnexpectedType): Error::Compressed
+        std::vector<uint8_t> packed(size_t(totals.out_bytes) + 64 * nb + 64);
+        std::vector<uint64_t> packed_off(nb + 1, 0);
+        std::vector<int32_t> status(nb ? nb : 1, 0);
+        nisshi_totals t2{};
+        st = nisshi_hip_deflate(codec.ctx(), out.data(), totals.out_bytes, out_off.data(), uint32_t(nb), want.data(),
+                                packed.data(), packed.size(), packed_off.data(), status.data(), &t2);
+        if (st) return Error::from_status(st);
+        for (size_t b = 0; b < nb; b++)
+            if (status[b] != NISSHI_OK) return Error::from_status(status[b], want[b]);
+        out.swap(packed);
+        out_off.swap(packed_off);
+        totals.out_bytes = t2.out_bytes;
+    }
     Bytes all(out.data(), size_t(totals.out_bytes));
     deflated::Frame f;
     f.batches.reserve(nb);

@@ -573,6 +573,39 @@ int nisshi_hip_inflate(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_l
                        const uint64_t *batch_off, uint32_t n_batches, uint8_t *out, uint64_t out_cap,
                        uint64_t *out_off, int32_t *status, nisshi_totals *totals);
 
+/* Batches compressed: into_record_data (nisshi-sans-io/src/record/deflated.rs:341-386), which
+ * deflated::Batch::try_from(inflated::Batch) (deflated.rs:392-409) calls with the batch's codec, for
+ * its Lz4 arm (deflated.rs:362-371: the lz4 crate's Encoder, liblz4's frame format).  A frame of
+ * uncompressed batches goes in -- what nisshi_hip_encode_dev writes -- and the same frame comes out
+ * with every batch whose d_codec[b] is 3 rewritten: its record data one LZ4 frame (independent
+ * blocks of 16 KiB, no checksums, no content size; a block that does not shrink is stored), its
+ * batch_length that of the frame, the codec in its attributes, its crc that of the new bytes.
+ * d_codec[b] 0: the batch is copied.  1 (gzip) and 4 (zstd), which the reference compresses, and 2
+ * (Snappy), which it refuses (Error::UnexpectedType): not produced here, the batch is copied as it
+ * came with NISSHI_COMPRESSED, for the caller's own path.  Above 4: copied, NISSHI_UNKNOWN_COMPRESSION.
+ * A batch to be compressed whose header does not hold (shorter than 61 bytes, a batch_length
+ * that is not its length, codec bits already set): copied, NISSHI_MALFORMED.
+ * Which bytes a compressor writes is its own choice (the reference holds no vector of compressed
+ * output); what holds is that the frame inflates to the record data it was made from -- by the
+ * reference's decoder (lib.rs:1752-1755), by nisshi_hip_inflate_dev, by the CPU checker -- and that
+ * the batch around it decodes like any compressed batch.
+ * With d_out == NULL the call only says how much room it needs: totals->out_bytes, every batch at
+ * its worst case (a few bytes a block more than uncompressed, and a KiB a batch of working room:
+ * the batches are compressed into a scratch area of that size).  Otherwise NISSHI_CAPACITY when
+ * out_cap is below that; d_out_off receives n_batches + 1 offsets into d_out, and
+ * totals->out_bytes the bytes of the frame, n_failed the batches whose status is not NISSHI_OK.
+ * totals must not be NULL: the call waits for the device twice. */
+int nisshi_hip_deflate_dev(nisshi_hip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_len,
+                           const uint64_t *d_batch_off, uint32_t n_batches, const uint8_t *d_codec,
+                           uint8_t *d_out, uint64_t out_cap, uint64_t *d_out_off, int32_t *d_status,
+                           nisshi_totals *totals, void *stream);
+
+/* The same for host buffers: copies in, compresses, copies out; out_cap is compared with the
+ * frame that came out (NISSHI_CAPACITY, with totals->out_bytes its size). */
+int nisshi_hip_deflate(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_len,
+                       const uint64_t *batch_off, uint32_t n_batches, const uint8_t *codec, uint8_t *out,
+                       uint64_t out_cap, uint64_t *out_off, int32_t *status, nisshi_totals *totals);
+
 /* Page-locked host memory for the host-buffer entry points: blobs and columns
  * in buffers from here move over PCIe by DMA at link speed; any other host
  * memory works too, staged by the HIP runtime and several times slower.  (The

@@ -188,6 +188,8 @@ extern "C" {
     pub fn nisshi_hip_pool_create_custom(n_devices: u32, decode: PoolDecodeFn, decoder_ctx: *const *mut c_void, pool: *mut *mut Pool) -> c_int;
     pub fn nisshi_hip_inflate_dev(ctx: *mut Ctx, d_blob: *const u8, blob_len: u64, d_batch_off: *const u64, n_batches: u32, d_out: *mut u8, out_cap: u64, d_out_off: *mut u64, d_status: *mut i32, totals: *mut Totals, stream: *mut c_void) -> c_int;
     pub fn nisshi_hip_inflate(ctx: *mut Ctx, blob: *const u8, blob_len: u64, batch_off: *const u64, n_batches: u32, out: *mut u8, out_cap: u64, out_off: *mut u64, status: *mut i32, totals: *mut Totals) -> c_int;
+    pub fn nisshi_hip_deflate_dev(ctx: *mut Ctx, d_blob: *const u8, blob_len: u64, d_batch_off: *const u64, n_batches: u32, d_codec: *const u8, d_out: *mut u8, out_cap: u64, d_out_off: *mut u64, d_status: *mut i32, totals: *mut Totals, stream: *mut c_void) -> c_int;
+    pub fn nisshi_hip_deflate(ctx: *mut Ctx, blob: *const u8, blob_len: u64, batch_off: *const u64, n_batches: u32, codec: *const u8, out: *mut u8, out_cap: u64, out_off: *mut u64, status: *mut i32, totals: *mut Totals) -> c_int;
     pub fn nisshi_hip_host_alloc(ctx: *mut Ctx, bytes: u64, ptr: *mut *mut c_void) -> c_int;
     pub fn nisshi_hip_host_free(ctx: *mut Ctx, ptr: *mut c_void);
     pub fn nisshi_hip_crc32c_dev(ctx: *mut Ctx, d_data: *const u8, len: u64, crc: *mut u32, stream: *mut c_void) -> c_int;

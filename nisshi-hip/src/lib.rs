@@ -417,6 +417,47 @@ impl Codec {
         Ok((out, out_off, status.into_iter().map(Status::from).collect(), totals))
     }
 
+    /// `nisshi_hip_deflate`: a frame of uncompressed batches (what `encode` writes) with every batch whose
+    /// `codec` is 3 compressed as `into_record_data`'s Lz4 arm does (deflated.rs:362-371): its record data one
+    /// LZ4 frame, `batch_length`, the codec bits and the crc to match.  `codec` 0: the batch as it came.  1, 2
+    /// and 4 are not produced on the device: the batch comes back as it went in with `Status::Compressed`, for
+    /// the caller's own `into_record_data`.  Returns the frame's bytes, the start of each batch and a status a batch.
+    pub fn deflate(&mut self, blob: &[u8], batch_off: &[u64], codec: &[u8]) -> Result<(Vec<u8>, Vec<u64>, Vec<Status>, Totals)> {
+        let n = Self::checked_batches(blob, batch_off, "nisshi_hip_deflate")?;
+        if codec.len() != n {
+            return Err(Error {
+                status: Status::InvalidArgument,
+                detail: format!("nisshi_hip_deflate: {} codecs for {n} batches", codec.len()),
+            });
+        }
+        let mut out_off = vec![0u64; n + 1];
+        let mut status = vec![0i32; n.max(1)];
+        let mut totals = Totals::default();
+        // (a batch grows by a few bytes a 16 KiB block at most)
+        let mut out = vec![0u8; blob.len() + blob.len() / 512 + 64 * n + 64];
+        let st = unsafe {
+            ffi::nisshi_hip_deflate(
+                self.ctx,
+                blob.as_ptr(),
+                blob.len() as u64,
+                batch_off.as_ptr(),
+                n as u32,
+                codec.as_ptr(),
+                out.as_mut_ptr(),
+                out.len() as u64,
+                out_off.as_mut_ptr(),
+                status.as_mut_ptr(),
+                &mut totals,
+            )
+        };
+        if st != ffi::NISSHI_OK {
+            return Err(self.fail(st, "nisshi_hip_deflate"));
+        }
+        out.truncate(totals.out_bytes as usize);
+        status.truncate(n);
+        Ok((out, out_off, status.into_iter().map(Status::from).collect(), totals))
+    }
+
     /// The raw context, for the `*_dev` entry points and the storage operators of `ffi`.
     pub fn as_ptr(&mut self) -> *mut ffi::Ctx {
         self.ctx

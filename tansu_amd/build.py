@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libnisshi_hip.so")
 SOURCES = ["nisshi_hip.hip"]
-DEPS = ["nisshi_hip.hip", "encode.inc", "storage.inc", "fetch.inc", "compact.inc", "inflate.inc", "api.inc", "pool.inc", "wire.h", "gf2_crc32c.h"]
+DEPS = ["nisshi_hip.hip", "encode.inc", "storage.inc", "fetch.inc", "compact.inc", "inflate.inc", "zstd.inc", "deflate.inc", "api.inc", "pool.inc", "wire.h", "gf2_crc32c.h"]
 
 
 def source_hash() -> str:

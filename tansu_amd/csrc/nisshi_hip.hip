@@ -2777,5 +2777,8 @@ __global__ void crc_buffer_finish_kernel(const uint8_t *data, uint64_t len, uint
 #include "fetch.inc"
 #include "compact.inc"
 #include "inflate.inc"
+namespace nisshi {
+#include "deflate.inc"
+}
 #include "api.inc"
 #include "pool.inc"

@@ -30,6 +30,7 @@ EXPORTS = [
     "nisshi_hip_produce_rows_dev", "nisshi_hip_produce_rows", "nisshi_hip_combine_dev",
     "nisshi_hip_combine", "nisshi_hip_fetch_batches_dev", "nisshi_hip_fetch", "nisshi_hip_builder_fields_dev",
     "nisshi_hip_compact_dev", "nisshi_hip_compact", "nisshi_hip_inflate_dev", "nisshi_hip_inflate",
+    "nisshi_hip_deflate_dev", "nisshi_hip_deflate",
     "nisshi_hip_pool_create", "nisshi_hip_pool_create_custom", "nisshi_hip_pool_destroy",
     "nisshi_hip_pool_device_count", "nisshi_hip_pool_device_of", "nisshi_hip_pool_last_error",
     "nisshi_hip_pool_last_times", "nisshi_hip_pool_decode",
@@ -162,6 +163,8 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_compact.argtypes = [vp, vp, u64, vp, u32, vp, vp, u64, vp, vp, vp, vp, ctypes.POINTER(Totals)]
     lib.nisshi_hip_inflate_dev.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp, vp, ctypes.POINTER(Totals), vp]
     lib.nisshi_hip_inflate.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp, vp, ctypes.POINTER(Totals)]
+    lib.nisshi_hip_deflate_dev.argtypes = [vp, vp, u64, vp, u32, vp, vp, u64, vp, vp, ctypes.POINTER(Totals), vp]
+    lib.nisshi_hip_deflate.argtypes = [vp, vp, u64, vp, u32, vp, vp, u64, vp, vp, ctypes.POINTER(Totals)]
     lib.nisshi_hip_pool_create.argtypes = [vp, u32, ctypes.POINTER(vp)]
     lib.nisshi_hip_pool_create_custom.argtypes = [u32, POOL_DECODE_FN, vp, ctypes.POINTER(vp)]
     lib.nisshi_hip_pool_destroy.argtypes = [vp]
@@ -531,6 +534,41 @@ class Codec:
             st = self.lib.nisshi_hip_inflate(self.ctx, arr.ctypes.data if len(arr) else None, len(arr),
                                              off.ctypes.data, n_b, out.ctypes.data, cap, out_off.ctypes.data,
                                              status.ctypes.data, ctypes.byref(totals))
+        self._check(st)
+        return out[:int(totals.out_bytes)].tobytes(), out_off, status[:n_b], totals
+
+    def deflate_dev(self, d_blob, blob_len: int, d_batch_off, n_batches: int, d_codec):
+        """A frame of uncompressed batches with those whose codec is 3 compressed (LZ4).  Asks for the room first,
+        then allocates the output: returns (d_out tensor, d_out_off tensor, d_status tensor, totals)."""
+        import torch
+        d_out_off = torch.zeros(n_batches + 1, dtype=torch.int64, device=self.device)
+        d_status = torch.zeros(max(n_batches, 1), dtype=torch.int32, device=self.device)
+        room = Totals()
+        self._check(self.lib.nisshi_hip_deflate_dev(
+            self.ctx, d_blob.data_ptr(), blob_len, d_batch_off.data_ptr(), n_batches, d_codec.data_ptr(), None, 0,
+            d_out_off.data_ptr(), d_status.data_ptr(), ctypes.byref(room), self._stream()))
+        d_out = torch.empty(room.out_bytes + 16, dtype=torch.uint8, device=self.device)
+        totals = Totals()
+        self._check(self.lib.nisshi_hip_deflate_dev(
+            self.ctx, d_blob.data_ptr(), blob_len, d_batch_off.data_ptr(), n_batches, d_codec.data_ptr(), d_out.data_ptr(),
+            room.out_bytes, d_out_off.data_ptr(), d_status.data_ptr(), ctypes.byref(totals), self._stream()))
+        return d_out, d_out_off, d_status, totals
+
+    def deflate(self, blob: bytes, batch_off, codec, out_cap: Optional[int] = None):
+        """Host bytes in, host bytes out: (frame bytes, out_off, status np.int32[n], totals)."""
+        arr = np.frombuffer(bytes(blob), dtype=np.uint8)
+        off = np.ascontiguousarray(batch_off, dtype=np.uint64)
+        n_b = len(off) - 1
+        cod = np.ascontiguousarray(codec, dtype=np.uint8)
+        assert len(cod) == n_b
+        out_off = np.zeros(n_b + 1, dtype=np.uint64)
+        status = np.zeros(max(n_b, 1), dtype=np.int32)
+        totals = Totals()
+        cap = len(arr) + 64 * n_b + 64 if out_cap is None else out_cap
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        st = self.lib.nisshi_hip_deflate(self.ctx, arr.ctypes.data if len(arr) else None, len(arr), off.ctypes.data, n_b,
+                                         cod.ctypes.data if n_b else None, out.ctypes.data, cap, out_off.ctypes.data,
+                                         status.ctypes.data, ctypes.byref(totals))
         self._check(st)
         return out[:int(totals.out_bytes)].tobytes(), out_off, status[:n_b], totals
 

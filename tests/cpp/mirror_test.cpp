@@ -163,6 +163,36 @@ static void inflate_compressed_batches(Codec &codec) {
     CHECK(bad.is_err() && bad.error().kind == Error::Malformed);
 }
 
+// deflated::Batch::try_from(inflated::Batch) of a batch whose attributes name a codec (deflated.rs:392-409 through
+// into_record_data, deflated.rs:341-386): LZ4 is compressed on the device and inflates to the same records; gzip and
+// zstd (which the reference compresses) and Snappy (which it refuses) are Error::Compressed here.
+static void deflate_with_a_codec(Codec &codec) {
+    auto d = deflated::Batch::try_from(Bytes(kLz4Batch, sizeof(kLz4Batch))).unwrap();
+    auto by_ref = inflated::Batch::try_from(codec, d).unwrap();  // attributes verbatim: codec 3
+    CHECK((by_ref.attributes & 7) == 3 && by_ref.records.size() == 1);
+    auto packed = deflated::Batch::try_from(codec, by_ref);
+    CHECK(packed.is_ok());
+    CHECK((packed->attributes & 7) == 3 && packed->record_count == 1 && packed->base_timestamp == d.base_timestamp);
+    CHECK(packed->batch_length == int32_t(49 + packed->record_data.len()));
+    CHECK(packed->record_data.len() < size_t(kLoremRecordLength) && packed->record_data[0] == 0x04 && packed->record_data[1] == 0x22);
+    auto back = inflated::Batch::try_from(codec, *packed);
+    CHECK(back.is_ok() && back->records == by_ref.records && back->attributes == by_ref.attributes);
+    // a frame of it between plain batches
+    inflated::Frame frame;
+    frame.batches.push_back(inflated::Batch::try_from(codec, deflated::Batch::try_from(Bytes(kBatch71, sizeof(kBatch71))).unwrap()).unwrap());
+    frame.batches.push_back(by_ref);
+    frame.batches.push_back(frame.batches[0]);
+    auto all = deflated::Frame::try_from(codec, frame);
+    CHECK(all.is_ok() && all->batches.size() == 3 && all->batches[1] == *packed);
+    CHECK(all->batches[0].into_bytes() == Bytes(kBatch71, sizeof(kBatch71)) && all->batches[2] == all->batches[0]);
+    for (int other : {1, 2, 4}) {
+        inflated::Batch b = by_ref;
+        b.attributes = int16_t((b.attributes & ~7) | other);
+        auto r = deflated::Batch::try_from(codec, b);
+        CHECK(r.is_err() && r.error().kind == Error::Compressed && r.error().detail == other);
+    }
+}
+
 static void records_with_keys_and_headers_round_trip(Codec &codec) {
     inflated::Frame frame;
     for (int b = 0; b < 3; b++) {
@@ -506,6 +536,7 @@ int main(int argc, char **argv) {
         inflate_batch(codec);
         attributes_by_value_and_by_reference(codec);
         inflate_compressed_batches(codec);
+        deflate_with_a_codec(codec);
         records_with_keys_and_headers_round_trip(codec);
         truncated_record_data_is_an_error(codec);
         combine_empty(codec);

@@ -17,4 +17,5 @@ echo "operators done"
 for c in snappy lz4 gzip zstd; do
   CODEC=$c timeout -k 10 300 python3 tools/inflate_time.py > $o/${tag}_inflate_$c.json 2> $o/${tag}_inflate_$c.err
 done
-echo "inflate done"
+timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate.json 2> $o/${tag}_deflate.err
+echo "inflate and deflate done"
