@@ -215,6 +215,22 @@ def test_large_batches_of_known_size_are_written_in_pieces(wide_codec, key_len, 
     assert got == want
 
 
+def test_host_buffers_carry_the_sizes_too(codec):
+    """nisshi_hip_decode hands the sizes back with the other columns and nisshi_hip_encode takes them (or none:
+    a caller's struct may leave the pointer NULL, which hip.py does when the column is missing)."""
+    shape, counts, seed = synth.config("c2", 0.002)
+    blob, off, nr, nh = synth.make_batches(shape, counts, seed)
+    cols, totals = codec.decode(blob.tobytes(), off)
+    n = len(off) - 1
+    assert (cols["enc_len"][:n] == cols["data_len"][:n] + 1).all()
+    c, want = checker_bytes(blob, off)
+    got, got_off, t = codec.encode(cols, blob.tobytes(), cols["data_off"])
+    assert got == want
+    without = {k: v for k, v in cols.items() if k != "enc_len"}
+    got2, _, _ = codec.encode(without, blob.tobytes(), cols["data_off"])
+    assert got2 == want
+
+
 def test_operators_forget_the_sizes(codec):
     """Batches written by combine carry no size: their records are not those that were sized."""
     shape, counts, seed = synth.config("c5", 0.01)
