@@ -125,8 +125,9 @@ typedef struct nisshi_columns {
      * nisshi_hip_encode_dev takes it from here instead of sizing those records again.  It is a
      * hint: the decode notes it in calls whose batches average NISSHI_WIDE_RING_FROM bytes and
      * more (see nisshi_hip_ctx_create), for batches walked by their records' shapes, whole or
-     * chunk by chunk; any other batch has 0 and is sized by the encode as before.  combine,
-     * compact and the fetch seam store 0 for the batches they write.  A caller that changes a
+     * chunk by chunk; any other batch has 0 and is sized by the encode as before.  The fetch
+     * seam, which works out every record's length anyway, leaves the sum for its batches of
+     * fewer than 2048 records; combine and compact store 0 for the batches they write.  A caller that changes a
      * batch's records by hand stores 0 too (or passes NULL): the encode trusts the value, and one
      * that is less than the records take makes it write past the batch's place in the output. */
     uint32_t *enc_len;

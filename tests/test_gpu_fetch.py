@@ -100,6 +100,25 @@ def test_many_rows(codec, kw):
     assert got == want
 
 
+def test_fetch_leaves_the_batches_sizes_for_the_encoder(codec):
+    """The fetch seam works out every record's length: the sum a batch is left in `enc_len` (bytes + 1) so that the
+    encode does not size the records again -- for batches of fewer than 2048 records; larger ones, which are
+    written in pieces, are sized by the encoder."""
+    rows, payload = make_rows(20000, seed=9, change_every=1700, gap_rate=0.1)
+    big, payload_big = make_rows(9000, seed=10, change_every=4000)
+    for r, pl in ((rows, payload), (big, payload_big)):
+        st, want = oracle.fetch(r, pl, NOW, batch_cap=8192)
+        d_rows, keep = codec.fetch_rows_to_device(r)
+        cols, nb = codec.fetch_batches_dev(d_rows, keep.get("hdr"), len(r["offset"]), NOW, 8192)
+        assert st == C.OK and nb == len(want)
+        enc_len = cols.t["enc_len"][:nb].cpu().numpy().view(np.uint32)
+        count = cols.t["record_count"][:nb].cpu().numpy()
+        expect = np.array([len(w) - 61 + 1 for w in want], dtype=np.uint32)
+        expect[count >= 2048] = 0
+        assert (enc_len == expect).all() and (enc_len != 0).any()
+    assert (expect == 0).any()
+
+
 def test_produce_then_fetch_round_trip(codec):
     """Rows written by the produce seam and read back by the fetch seam carry the
     same records: the batch's records at offsets high .. high + n - 1."""
