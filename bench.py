@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c2v", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c2v", "c3", "c4", "c5", "c5g"])
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-copies", action="store_true",
@@ -112,7 +112,7 @@ def main():
     # ---- this rank's shard: its own topic-partitions, same shape, own seed
     shape, blob, off, n_records, n_headers, n_batches = shard.make_shard(args.workload, args.scale, rank, world)
     host_split = None
-    if args.workload == "c5":
+    if args.workload in ("c5", "c5g"):
         # C5 arrives as produce requests: the batches wrapped as ProduceRequest v11
         # partition data, found again on the host (one call over all records fields:
         # prefix decode and frame split) before the buffer goes to the device as it is
@@ -227,7 +227,9 @@ def main():
                          "c3": "C3: large values, 1 MiB values, 4 records/batch",
                          "c4": "C4: mixed topic-partitions (five shapes by p mod 5, 64 batches each), 128 a GPU",
                          "c5": "C5: ragged batches, 1-10k records of 100 B, as ProduceRequest v11 partition data "
-                               "(1-8 partitions a request, 1-4 batches a records field)"}[args.workload],
+                               "(1-8 partitions a request, 1-4 batches a records field)",
+                         "c5g": "C5 after a compaction that took every third record of every batch (offset deltas "
+                                "0, 1, 3, 4, 6, ...), as ProduceRequest v11 partition data"}[args.workload],
             "batches_per_gpu": n_batches,
             "records_per_gpu": n_records,
             "input_bytes_per_gpu": in_bytes,

@@ -168,6 +168,13 @@ int nisshi_hip_ctx_create(int device, nisshi_hip_ctx **ctx);
 void nisshi_hip_ctx_destroy(nisshi_hip_ctx *ctx);
 const char *nisshi_hip_status_str(int status);
 const char *nisshi_hip_last_error(const nisshi_hip_ctx *ctx);
+/* Of the context's last decode that handed back totals: the batches that were
+ * decoded a wave a 64 KiB chunk on guesses that did not hold (see the decode,
+ * below) and so were walked once more, whole, by one wave.  Same columns either
+ * way; a number that stays high says the call's large batches are not what the
+ * chunks' guesses expect.  (Not counted in calls of small batches, mean size
+ * below NISSHI_WIDE_RING_FROM.)  No counterpart in the reference. */
+uint64_t nisshi_hip_last_walked_whole(const nisshi_hip_ctx *ctx);
 
 /* Host-side framing of a records blob (de.rs:1056-1093): writes the start of
  * every batch plus the end of the last one (n + 1 entries). */

@@ -159,6 +159,7 @@ extern "C" {
     pub fn nisshi_hip_ctx_destroy(ctx: *mut Ctx);
     pub fn nisshi_hip_status_str(status: c_int) -> *const c_char;
     pub fn nisshi_hip_last_error(ctx: *const Ctx) -> *const c_char;
+    pub fn nisshi_hip_last_walked_whole(ctx: *const Ctx) -> u64;
     pub fn nisshi_frame_split(blob: *const u8, len: u64, batch_off: *mut u64, cap: u64, n_batches: *mut u64) -> c_int;
     pub fn nisshi_records_prefix_decode(buf: *const u8, len: u64, flexible: c_int, pos: *mut u64, records_len: *mut u32, is_null: *mut c_int) -> c_int;
     pub fn nisshi_records_prefix_encode(records_len: u32, flexible: c_int, out: *mut u8) -> u64;

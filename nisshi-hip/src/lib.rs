@@ -223,6 +223,12 @@ impl Codec {
         Ok(Self { ctx })
     }
 
+    /// Batches of the last decode that were decoded chunk by chunk on guesses
+    /// that did not hold, and so walked once more by one wave.
+    pub fn last_walked_whole(&self) -> u64 {
+        unsafe { ffi::nisshi_hip_last_walked_whole(self.ctx) }
+    }
+
     fn fail(&self, st: c_int, what: &str) -> Error {
         let detail = unsafe {
             let p = ffi::nisshi_hip_last_error(self.ctx);

@@ -46,6 +46,7 @@ constexpr uint32_t kFlagExact = 1u;   // needs the sequential walk
 constexpr uint32_t kFlagMore = 2u;    // more headers than the slots it was expected to need: walked again
 constexpr uint32_t kFlagChunks = 8u;  // the batch's chunks are work items of chunk_kernel: its CRC comes from their residues
 constexpr uint32_t kFlagSeg = 4u;     // CRC and records chunk by chunk, a wave each (chunk_kernel); decode_fused_kernel checks that the chunks join up
+constexpr uint32_t kFlagGap = 16u;    // such a batch whose records are not numbered 0, 1, 2 ...: a chunk's first index comes from chunk_index_kernel
 
 struct Work {
     uint32_t *alloc_count;  // record slots the batch gets
@@ -72,12 +73,14 @@ struct Work {
                             // [6] end of the expected header slots [7] entries of `list`
     uint64_t *tile_sum;     // the scans over very many batches: two sums a tile of kScanTile batches
     uint32_t *shape_guess;  // kShapeWords words a block of kSumBlock batches: the shape of the first record of the block's first batch (guess_shape)
-    uint32_t *chunk_done;   // encode: the CRC work item has its residue already (from the copy of a long span)
+    uint32_t *chunk_done;   // encode: the CRC work item has its residue already (from the copy of a long span); decode: the records
+                            // that start in the chunk, of batches whose chunks are counted first (chunk_index_kernel)
     // Two words of page-locked host memory that the call leaves for the host's next call: [0] the entries
     // its list had, [1] the CRC work items its large batches have (or would have had).  May be NULL.
     uint32_t *hint;
 };
 
+constexpr uint32_t kModeChunks = 1u, kModeGaps = 2u, kModeShift = 2;  // batch_header_kernel's `mode`: the call's launches, and its number above them
 constexpr uint32_t kBigChunks = 8;        // from this many 64 KiB chunks on a batch's CRC is taken chunk by chunk
 constexpr uint32_t kSegChunks = 2;        // from this many on, a batch of small records may be decoded chunk by chunk too
 constexpr uint32_t kSegRecordMax = 1024;  // "small": the first record has at most this many bytes
@@ -148,7 +151,7 @@ __device__ inline uint64_t block_exclusive_scan64(uint64_t v, uint64_t *lds, uin
 // it is expected to need (high half).
 __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t *batch_off, uint32_t b, int by_value,
                                             const nisshi_columns &c, const Work &w, uint32_t count_small,
-                                            uint32_t seg_chunks, bool chunks_on, uint32_t &chunk_items) {
+                                            uint32_t seg_chunks, uint32_t mode, uint32_t &chunk_items) {
     const uint8_t *p = blob + batch_off[b];
     uint64_t len = batch_off[b + 1] - batch_off[b];
     int st = NISSHI_OK;
@@ -305,10 +308,18 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
     // large batch of anything else gets its CRC from its chunks and its records
     // from one wave.  Either way its chunks are work items.
     bool segmented = fits && chunks >= seg_chunks && first_size != 0 && first_size <= kSegRecordMax;
-    // (chunks_on false: the call has no launch that works on chunks -- the call before it had no such
+    // A batch that does not number its records 0, 1, 2 ... (a compacted one: last_offset_delta + 1 is not
+    // its record count) has its chunks' first indices counted by a launch of its own, chunk_index_kernel,
+    // which a call has when the call before it saw such a batch (kModeGaps): the call's number is left
+    // where the host finds it.  Without that launch the batch is one wave's.
+    bool gapped = segmented && (uint32_t)lod + 1 != record_count;
+    if (gapped && w.hint != nullptr) w.hint[3] = mode >> kModeShift;
+    bool by_chunk = segmented && (!gapped || (mode & kModeGaps));
+    // (kModeChunks not set: the call has no launch that works on chunks -- the call before it had no such
     // batch; the items are still counted, for the call after this one, and the batch is one wave's)
     chunk_items = segmented || chunks >= kBigChunks ? chunks : 0;
-    if (chunk_items && chunks_on) w.flags[b] |= segmented ? kFlagSeg | kFlagChunks : kFlagChunks;
+    if (chunk_items && (mode & kModeChunks))
+        w.flags[b] |= !by_chunk ? kFlagChunks : gapped ? kFlagSeg | kFlagChunks | kFlagGap : kFlagSeg | kFlagChunks;
     w.hdr_need[b] = 0;
     return ((uint64_t)expect << 32) | (fits ? record_count : 0u);
 }
@@ -319,7 +330,7 @@ __device__ inline void guess_shape(const uint8_t *blob, const uint64_t *batch_of
 // there) each leave a guess at the shape of their block's records: guess_shape.
 __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
                                     int by_value, nisshi_columns c, Work w, uint32_t count_small, uint32_t seg_chunks,
-                                    uint32_t chunks_on) {
+                                    uint32_t mode) {
     __shared__ uint64_t wave_sums[kSumBlock >> 6];
     uint32_t n_blocks = (n + kSumBlock - 1) / kSumBlock;
     if (blockIdx.x >= n_blocks) {
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *
     if (b < 8) w.totals[b] = 0;
     uint64_t mine = 0;  // record slots in the low half, expected header slots in the high half
     uint32_t items = 0;  // CRC work items: those of large batches
-    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, seg_chunks, chunks_on != 0, items);
+    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, seg_chunks, mode, items);
     uint64_t total;
     uint64_t before = block_exclusive_scan64(mine, wave_sums, total);
     if (b < n) {
@@ -2105,10 +2116,11 @@ constexpr uint32_t kSegNone = 0xfffffffeu;  // no record starts in the chunk: ri
 constexpr uint32_t kSegScanBytes = kSegRecordMax + 64;
 
 // One record's claim to be a record, at byte q of the record data: its size and
-// its offset delta.  Only a filter; nothing is concluded from it.
-template <int kRows>
-__device__ __forceinline__ bool plausible_record(const RingView<kRows> &ring, uint32_t bias, uint32_t q, uint32_t data_len,
-                                                 uint32_t &size, int32_t &od) {
+// its offset delta.  Only a filter; nothing is concluded from it.  View: where the
+// bytes are read, read64(position + bias) -- the wave's ring, or the batch in memory.
+template <class View>
+__device__ __forceinline__ bool plausible_record(const View &ring, uint32_t bias, uint32_t q, uint32_t data_len,
+                                                 uint32_t &size, int32_t &od, uint32_t *key_at = nullptr) {
     uint32_t used, t_used, o_used;
     int32_t len;
     int64_t ts;
@@ -2120,30 +2132,69 @@ __device__ __forceinline__ bool plausible_record(const RingView<kRows> &ring, ui
     ok = fast_varlong((uint32_t)ring.read64(at + bias), t_used, ts) && ok;
     at += ok ? t_used : 0;
     ok = fast_varint(ring.read64(at + bias), o_used, od) && ok;
+    if (key_at) *key_at = at + o_used;
     return ok && od >= 0;
+}
+
+// Whether the fields of a plausible record of `size` bytes at q, from the key's
+// length at `at` on, end where the record's length says (the headers of a record
+// of more than kHoldsHeaders are not followed: it only must not have ended yet).
+// A filter as well, for find_record_start where the deltas say less.
+constexpr int kHoldsHeaders = 8;
+template <class View>
+__device__ __forceinline__ bool record_holds(const View &ring, uint32_t bias, uint32_t q, uint32_t size, uint32_t at, bool ok) {
+    uint32_t end = q + size, used;
+    int32_t v, hc;
+    for (int span = 0; span < 2; span++) {  // the key, the value: a length (-1: null) and its bytes
+        ok = fast_varint(ring.read64((ok ? at : 0u) + bias), used, v) && ok && v >= -1 && (v < 0 || (uint32_t)v <= size);
+        at += ok ? used + (v > 0 ? (uint32_t)v : 0u) : 0u;
+        ok = ok && at < end;
+    }
+    ok = fast_varint(ring.read64((ok ? at : 0u) + bias), used, hc) && ok && hc >= 0;
+    at += ok ? used : 0u;
+#pragma unroll 1
+    for (int h = 0; h < 2 * kHoldsHeaders; h++) {  // a header's key, then its value
+        bool more = ok && h < 2 * hc;
+        if (!__any(more)) break;
+        bool is = fast_varint(ring.read64((more ? at : 0u) + bias), used, v) && v >= -1 && (v < 0 || (uint32_t)v <= size);
+        ok = ok && (!more || is);
+        at += more && is ? used + (v > 0 ? (uint32_t)v : 0u) : 0u;
+        ok = ok && at <= end;
+    }
+    return ok && (hc <= kHoldsHeaders ? at == end : at <= end);
 }
 
 // The first position in [x, x + kSegScanBytes) of the record data where three
 // records in a row are plausible, with offset deltas that count up by one (fewer
-// when the batch's last record comes first).  The ring holds the rows that cover
-// the scan and three records of kSegRecordMax bytes behind it.
-template <int kRows>
-__device__ __forceinline__ bool find_record_start(const RingView<kRows> &ring, uint32_t bias, uint32_t x, uint32_t data_len,
-                                                  uint32_t count, int lane, uint32_t &pos0, uint32_t &k0) {
+// when the batch's last record comes first); `gapped`, of a batch that does not
+// number its records 0, 1, 2 ...: with offset deltas that grow, none above the
+// batch's last, `lod` (fewer when the record data ends), the first of the three
+// with fields that end where its length says (record_holds).  The view holds the rows
+// that cover the scan and three records of kSegRecordMax bytes behind it.
+template <class View>
+__device__ __forceinline__ bool find_record_start(const View &ring, uint32_t bias, uint32_t x, uint32_t data_len,
+                                                  uint32_t count, int lane, uint32_t &pos0, uint32_t &k0,
+                                                  bool gapped = false, uint32_t lod = 0) {
     for (uint32_t base = x; base < x + kSegScanBytes; base += kWave) {
         uint32_t q = base + (uint32_t)lane, size;
         int32_t od0, od;
-        bool ok = plausible_record(ring, bias, q, data_len, size, od0);
-        ok = ok && size <= kSegRecordMax && (uint32_t)od0 < count;
+        uint32_t key_at;
+        bool ok = plausible_record(ring, bias, q, data_len, size, od0, &key_at);
+        ok = ok && size <= kSegRecordMax && (gapped ? (uint32_t)od0 <= lod : (uint32_t)od0 < count);
+        // (deltas that only have to grow say little: bytes that end on the next record's first
+        // byte would do for a first record, were their fields not looked at)
+        if (gapped) ok = record_holds(ring, bias, q, size, key_at, ok);
         uint32_t next = q + size;
         int32_t want = od0 + 1;
 #pragma unroll 1
         for (int hop = 0; hop < 2; hop++) {
-            bool more = ok && (uint32_t)want < count;  // the batch's last record has none behind it
+            // the batch's last record has none behind it
+            bool more = ok && (gapped ? next < data_len : (uint32_t)want < count);
             bool good = plausible_record(ring, bias, more ? next : 0u, data_len, size, od);
-            ok = ok && (!more || (good && od == want && size <= kSegRecordMax));
+            good = good && size <= kSegRecordMax && (gapped ? od >= want && (uint32_t)od <= lod : od == want);
+            ok = ok && (!more || good);
             next += more ? size : 0;
-            want += 1;
+            want = gapped && more ? od + 1 : want + 1;
         }
         uint64_t found = __ballot(ok);
         if (found) {
@@ -2154,6 +2205,135 @@ __device__ __forceinline__ bool find_record_start(const RingView<kRows> &ring, u
         }
     }
     return false;
+}
+
+// ---- the first record index of every chunk of a batch that does not number its
+// records 0, 1, 2 ... (kFlagGap): counted ahead of the chunks' walk, a wave a chunk.
+//
+// The wave finds the chunk's first record as the chunk's walk will (find_record_start
+// over the batch in memory) and counts the records that start in the chunk without
+// walking them: records of one size S lie S bytes apart, so the lanes look at 64
+// places at once -- is there a record of S bytes at start + i S? -- spread over the
+// chunk; where one is not, the places between it and the last that was are looked at
+// the same way until the first record of another size is known, and the count goes
+// on from it with its size (a producer's records grow a byte where a delta does).
+// Places not looked at are taken to hold records: the count is a guess, as the
+// chunk's start is, and segments_join checks both -- a chunk's walk ends at the
+// record index that the next one started with only if every count before was right.
+// A chunk whose sizes change more often than kIndexTries times is not counted
+// (kSegFailed: the batch is then one wave's).
+constexpr int kIndexTries = 16;
+
+// The batch in memory.  A read keeps the 32 bytes around it in registers: the head
+// of a record -- its length, attributes and deltas -- is then one trip to memory.
+struct MemoryView {
+    const uint8_t *grid;  // the 16-byte boundary at or below the batch's first CRC byte
+    uint32_t limit;       // bytes from there that may be read: to the end of the 16 bytes that hold the batch's last
+    mutable uint32_t held_at = 0xffffffffu;  // where the words held start (a multiple of 8)
+    mutable uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    __device__ __forceinline__ MemoryView(const uint8_t *grid_, uint32_t limit_) : grid(grid_), limit(limit_) {}
+    __device__ __forceinline__ uint64_t word(uint32_t at) const {
+        return at + 8 <= limit ? *reinterpret_cast<const uint64_t *>(grid + at) : 0;
+    }
+    __device__ __forceinline__ uint64_t read64(uint32_t at) const {
+        uint32_t a = at & ~7u, sh = (at & 7u) * 8;
+        if (a - held_at > 16u) {  // (below what is held wraps to a large number)
+            held_at = a;
+            h0 = word(a), h1 = word(a + 8), h2 = word(a + 16), h3 = word(a + 24);
+        }
+        uint32_t d = a - held_at;  // 0, 8 or 16
+        uint64_t a0 = d & 16 ? h2 : h0, a1 = d & 16 ? h3 : h1;
+        uint64_t lo = d & 8 ? a1 : a0, hi = d & 8 ? h2 : a1;
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    }
+};
+
+// A stretch of the batch copied to LDS, kIndexStretch bytes from byte `origin` on
+// (a multiple of 16): what find_record_start reads around a chunk's first byte.
+constexpr uint32_t kIndexStretch = 5 * kWave * 16;
+static_assert(kIndexStretch >= kSegScanBytes + 3 * kSegRecordMax + 80 + 16 + 32, "the scan, three records behind it, a record's head");
+struct StretchView {
+    const lds_u32 *buf;
+    uint32_t origin;
+    __device__ __forceinline__ uint64_t read64(uint32_t at) const {
+        uint32_t o = at - origin;
+        o = o < kIndexStretch ? o : 0u;  // (positions of lanes that are not looked at)
+        const lds_u32 *p = buf + (o >> 2);
+        uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3);
+        uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3);
+        return ((uint64_t)hi << 32) | lo;
+    }
+};
+
+// The records that start in chunk `chunk` of batch b (kSegFailed: not counted).
+// buf: kIndexStretch + 16 bytes of LDS of the wave's own.
+__device__ __forceinline__ uint32_t chunk_record_count(const uint8_t *blob, const uint64_t *batch_off, uint32_t b, uint32_t chunk,
+                                                       uint32_t chunks, const nisshi_columns &c, lds_u32 *buf, int lane) {
+    // (everything that b alone gives is asked for at once)
+    uint64_t off_v = batch_off[b];
+    uint32_t length_v = (uint32_t)c.batch_length[b], data_len_v = c.data_len[b], count_v = c.record_count[b];
+    uint32_t lod_v = (uint32_t)c.last_offset_delta[b];
+    uint64_t lo = (((uint64_t)uni((uint32_t)(off_v >> 32)) << 32) | uni((uint32_t)off_v)) + 21, hi = lo + uni(length_v) - 9;
+    uint32_t data_len = uni(data_len_v), count = uni(count_v), lod = uni(lod_v);
+    uint64_t grid = lo & ~uint64_t(15);
+    MemoryView view(blob + grid, (((uint32_t)(hi - grid) - 1) & ~15u) + 16);
+    uint32_t bias = 40 + (uint32_t)(lo - grid);
+    uint32_t row0 = chunk * kChunkRows;
+    uint32_t x = chunk ? row0 * kRowBytes - bias : 0;
+    uint32_t pos_end = chunk + 1 < chunks ? (row0 + kChunkRows) * kRowBytes - bias : data_len;
+    pos_end = pos_end < data_len ? pos_end : data_len;
+    uint32_t pos = 0, unused;
+    if (x >= data_len) return 0;
+    StretchView near{buf, 0xffffffffu};
+    if (chunk) {
+        uint32_t origin = (x + bias) & ~15u;
+        u32x4 rows[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            uint32_t at = origin + (uint32_t)(j * kWave + lane) * 16;
+            rows[j] = at + 16 <= view.limit ? *reinterpret_cast<const u32x4 *>(view.grid + at) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++) *(lds_u128 *)(buf + (j * kWave + lane) * 4) = rows[j];
+        if (lane < 4) buf[kIndexStretch / 4 + lane] = 0;
+        lds_order();
+        near.origin = origin;
+        if (!find_record_start(near, bias, x, data_len, count, lane, pos, unused, true, lod)) return 0;
+    }
+    pos = uni(pos);
+    uint32_t counted = 0;
+    for (int tries = 0; tries < kIndexTries; tries++) {
+        if (pos >= pos_end) return counted;
+        uint32_t size;
+        int32_t od;
+        bool held = chunk && pos + bias - near.origin + 32 <= kIndexStretch;  // (the chunk's first record is)
+        if (!(held ? plausible_record(near, bias, pos, data_len, size, od) : plausible_record(view, bias, pos, data_len, size, od)))
+            return kSegFailed;
+        size = uni(size);
+        // records 0 .. m - 1 of this size from pos on start before the chunk's end; record 0 is there
+        uint32_t m = (pos_end - pos + size - 1) / size, good_to = 0, bad_at = m;
+        while (bad_at - good_to > 1) {
+            uint32_t between = bad_at - good_to - 1, step = (between + kWave - 1) / kWave;
+            uint32_t i = lane == kWave - 1 ? bad_at - 1 : good_to + 1 + (uint32_t)lane * step;
+            bool looked = i < bad_at;
+            uint32_t sz;
+            bool is = plausible_record(view, bias, looked ? pos + i * size : pos, data_len, sz, od) && sz == size;
+            uint64_t bad = __ballot(looked && !is);
+            if (!bad) {
+                good_to = bad_at - 1;
+            } else {
+                uint32_t f = (uint32_t)__ffsll((long long)bad) - 1;
+                uint64_t before = __ballot(looked) & ((1ull << f) - 1);
+                bad_at = (uint32_t)__builtin_amdgcn_readlane((int)i, (int)f);
+                if (before) good_to = (uint32_t)__builtin_amdgcn_readlane((int)i, 63 - __builtin_clzll(before));
+            }
+        }
+        counted += good_to + 1;
+        pos += (good_to + 1) * size;
+        if (good_to + 1 == m) return counted;
+    }
+    return kSegFailed;
 }
 
 // Whether the chunks of batch b, whose work items start at `first`, join up.
@@ -2241,13 +2421,20 @@ struct ChunkItems {
             base = (uint32_t)__builtin_amdgcn_readlane((int)(m1 ? ex1 : ex0), (int)top);
         }
         uint32_t local = item - base;
-        uint32_t lo_b = blk * kSumBlock, hi_b = lo_b + kSumBlock < n ? lo_b + kSumBlock : n;
-        while (hi_b - lo_b > 1) {  // largest batch of the block whose first item is <= local
-            uint32_t mid = (lo_b + hi_b) >> 1;
-            if (w.chunk_base[mid] <= local) lo_b = mid; else hi_b = mid;
-        }
-        b = uni(lo_b);
-        chunk = uni(local - w.chunk_base[lo_b]);
+        // the largest batch of the block whose first item is <= local: the first items
+        // only grow, so that is as many batches in as there are such first items, all
+        // looked at at once (four a lane)
+        static_assert(kSumBlock == 4 * kWave, "a lane looks at four batches of the block");
+        uint32_t lo_b = blk * kSumBlock, at_b = lo_b + 4 * (uint32_t)lane, found = 0;
+        uint32_t first[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) first[j] = at_b + j < n ? w.chunk_base[at_b + j] : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 4; j++) found += (uint32_t)__popcll(__ballot(first[j] <= local));
+        uint32_t in = uni(found - 1);  // (the block's first batch has first item 0)
+        b = lo_b + in;
+        uint32_t mine = first[in & 3];
+        chunk = uni(local - (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(in >> 2)));
     }
 };
 
@@ -2318,6 +2505,10 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, chunks, w.partial + first_item, t, lane);
         if (lane == 0) c.crc_computed[b] = v;
         joined_up = (flags & kFlagSeg) && status == NISSHI_OK && segments_join(w, first_item, chunks, count, lane, &sized);
+        // (counted: batches whose chunks did not join up, walked whole below; not by the kernel of
+        // small batches, which has no register to spare)
+        if (kRows != 8 && (flags & kFlagSeg) && status == NISSHI_OK && !joined_up && lane == 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 5), 1ull);
 #ifdef NISSHI_DIAG_JOINS  // diagnostic builds only: batches whose chunks did not join up, counted as sequential walks
         if ((flags & kFlagSeg) && !joined_up && lane == 0) {
             atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 3), 1ull);
@@ -2407,13 +2598,29 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     bool none = false;  // seg: no record starts in the chunk
     if (seg && do_walk) {
         lds_order();
+        bool gapped = (flags & kFlagGap) != 0;
         if (chunk) {
             uint32_t data_len = uni(c.data_len[b]);
-            do_walk = x < data_len && find_record_start(RingView<kRows>{stream.ring}, bias, x, data_len, count, lane, pos0, k0);
+            uint32_t lod = gapped ? uni((uint32_t)c.last_offset_delta[b]) : 0u;
+            do_walk = x < data_len &&
+                      find_record_start(RingView<kRows>{stream.ring}, bias, x, data_len, count, lane, pos0, k0, gapped, lod);
             none = !do_walk;
         }
         pos0 = uni(pos0);
         k0 = uni(k0);
+        if (gapped && chunk) {
+            // the records of the chunks before this one, as chunk_index_kernel counted them
+            uint32_t sum = 0;
+            bool known = true;
+            for (uint32_t j = (uint32_t)lane; j < chunk; j += kWave) {
+                uint32_t v = w.chunk_done[mine - chunk + j];
+                known = known && v != kSegFailed;
+                sum += v;
+            }
+            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            k0 = uni(sum);
+            if (!__all(known)) do_walk = none = false;  // (kSegFailed below)
+        }
         // every record is taken to have the header count of the batch's first: the chunk's headers start k0 such records in
         uint32_t hc = count ? expect / count : 0;
         hdr_first += k0 * hc;
@@ -2527,6 +2734,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                                shape_tab, lane);
         else
             crc_chunk_one(item, b, chunk, blob, batch_off, c.batch_length, c.crc_computed, w, t, lane);
+    }
+}
+
+// The chunks of batches that do not number their records 0, 1, 2 ..., a wave each
+// (as many passes as the grid needs), ahead of the launch that walks the chunks:
+// how many records start in the chunk (chunk_record_count), from which the chunk's
+// wave has the index of its first record.
+__global__ __launch_bounds__(64) void chunk_index_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
+                                                         nisshi_columns c, Work w, uint32_t prefixed) {
+    __shared__ __attribute__((aligned(16))) uint32_t stretch[kIndexStretch / 4 + 4];
+    int lane = threadIdx.x & 63;
+    ChunkItems items;
+    items.init(w, n, prefixed != 0, lane);
+    for (uint32_t item = blockIdx.x; item < items.total; item += gridDim.x) {
+        uint32_t b, chunk;
+        items.locate(w, item, lane, b, chunk);
+        uint32_t flags_v = w.flags[b], chunks_v = w.n_chunks[b];
+        if (!(uni(flags_v) & kFlagGap)) continue;
+        uint32_t counted = chunk_record_count(blob, batch_off, b, chunk, uni(chunks_v), c, (lds_u32 *)stretch, lane);
+        if (lane == 0) w.chunk_done[item] = counted;
+        lds_order();
     }
 }
 

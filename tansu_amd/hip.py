@@ -21,7 +21,7 @@ ABI_VERSION = 2     # NISSHI_HIP_ABI_VERSION of the header these bindings follow
 
 EXPORTS = [
     "nisshi_hip_abi_version", "nisshi_hip_ctx_create", "nisshi_hip_ctx_destroy", "nisshi_hip_status_str",
-    "nisshi_hip_last_error", "nisshi_frame_split", "nisshi_records_prefix_decode",
+    "nisshi_hip_last_error", "nisshi_hip_last_walked_whole", "nisshi_frame_split", "nisshi_records_prefix_decode",
     "nisshi_records_prefix_encode", "nisshi_records_fields_split", "nisshi_hip_count_dev", "nisshi_hip_decode_dev",
     "nisshi_hip_decode_dev_static",
     "nisshi_hip_encode_dev", "nisshi_hip_decode", "nisshi_hip_encode", "nisshi_hip_crc32c_dev",
@@ -128,6 +128,8 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_status_str.restype = ctypes.c_char_p
     lib.nisshi_hip_last_error.argtypes = [vp]
     lib.nisshi_hip_last_error.restype = ctypes.c_char_p
+    lib.nisshi_hip_last_walked_whole.argtypes = [vp]
+    lib.nisshi_hip_last_walked_whole.restype = ctypes.c_uint64
     lib.nisshi_frame_split.argtypes = [vp, u64, vp, u64, ctypes.POINTER(u64)]
     lib.nisshi_records_prefix_decode.argtypes = [vp, u64, i32, ctypes.POINTER(u64),
                                                  ctypes.POINTER(u32), ctypes.POINTER(i32)]
@@ -324,6 +326,10 @@ class Codec:
     def _check(self, st):
         if st:
             raise NisshiError(st, (self.lib.nisshi_hip_last_error(self.ctx) or b"").decode())
+
+    def last_walked_whole(self) -> int:
+        """Batches of the last decode whose chunks' guesses did not hold (walked whole by one wave)."""
+        return int(self.lib.nisshi_hip_last_walked_whole(self.ctx))
 
     def _stream(self):
         import torch

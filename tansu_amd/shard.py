@@ -77,7 +77,8 @@ def make_shard(workload: str, scale: float, rank: int, world: int = 1):
     if workload == "c2v":
         blob, off, n_records, n_headers = synth.make_var_batches(len(counts), int(counts[0]), shard_seed(seed, rank))
         return shape, blob, off, n_records, n_headers, len(counts)
-    blob, off, n_records, n_headers = synth.make_batches(shape, counts, shard_seed(seed, rank))
+    blob, off, n_records, n_headers = synth.make_batches(shape, counts, shard_seed(seed, rank),
+                                                         delta=synth.DELTAS.get(workload))
     return shape, blob, off, n_records, n_headers, len(counts)
 
 

@@ -65,6 +65,7 @@ class Shape:
     hval_len: int = 16
 
     def body(self, i: int) -> int:
+        """Bytes of a record whose two deltas are i, without its length varint."""
         n = 1 + len(varint(i)) + len(varint(i))
         for ln in (self.key_len, self.val_len):
             n += len(varint(ln)) + max(ln, 0)
@@ -74,11 +75,19 @@ class Shape:
         return n
 
 
-class Template:
-    """record_data of a batch of `r_max` records of one shape, payload bytes zero."""
+def every_third_missing(i: int) -> int:
+    """The deltas of a batch that lost every third record (2, 5, 8, ...) to
+    compaction: 0, 1, 3, 4, 6, 7, ..."""
+    return i + i // 2
 
-    def __init__(self, shape: Shape, r_max: int):
+
+class Template:
+    """record_data of a batch of `r_max` records of one shape, payload bytes zero.
+    `delta(i)`: the offset delta and timestamp delta of record i (default: i)."""
+
+    def __init__(self, shape: Shape, r_max: int, delta=None):
         self.shape, self.r_max = shape, r_max
+        self.delta = delta or (lambda i: i)
         parts = []
         mask_parts = []
         ends = np.zeros(r_max, dtype=np.int64)
@@ -86,8 +95,8 @@ class Template:
         hdr = (varint(shape.hkey_len), varint(shape.hval_len))
         # records of the same index width share their layout: build per distinct (varint(i) size)
         for i in range(r_max):
-            vi = varint(i)
-            body = shape.body(i)
+            vi = varint(self.delta(i))
+            body = shape.body(self.delta(i))
             rec = bytearray()
             m = bytearray()
 
@@ -127,14 +136,16 @@ class Template:
 
 
 def batch_header(base_offset: int, data_len: int, record_count: int, attributes: int = 0,
-                 crc: int = 0) -> bytes:
+                 crc: int = 0, last_delta: int = None) -> bytes:
+    if last_delta is None:
+        last_delta = max(record_count - 1, 0)
     return struct.pack(">qiibIhiqqqhiI", base_offset, 49 + data_len, -1, 2, crc, attributes,
-                       max(record_count - 1, 0), BASE_TIMESTAMP,
-                       BASE_TIMESTAMP + max(record_count - 1, 0), -1, -1, -1, record_count)
+                       last_delta, BASE_TIMESTAMP, BASE_TIMESTAMP + last_delta, -1, -1, -1, record_count)
 
 
-def make_batches(shape: Shape, counts, seed: int, template: Template = None):
-    """Build a blob of len(counts) batches; batch b has counts[b] records.
+def make_batches(shape: Shape, counts, seed: int, template: Template = None, delta=None):
+    """Build a blob of len(counts) batches; batch b has counts[b] records, record i
+    of a batch the deltas delta(i) (default: i).
 
     Returns (blob np.uint8[], batch_off np.uint64[n + 1], n_records, n_headers).
     CRC fields are zero (see patch_crc).
@@ -142,7 +153,8 @@ def make_batches(shape: Shape, counts, seed: int, template: Template = None):
     counts = np.asarray(counts, dtype=np.int64)
     r_max = int(counts.max()) if len(counts) else 0
     if template is None:
-        template = Template(shape, max(r_max, 1))
+        template = Template(shape, max(r_max, 1), delta)
+    delta = template.delta
     lens = np.array([61 + template.data_len(int(r)) for r in counts], dtype=np.int64)
     off = np.zeros(len(counts) + 1, dtype=np.uint64)
     off[1:] = np.cumsum(lens)
@@ -154,11 +166,11 @@ def make_batches(shape: Shape, counts, seed: int, template: Template = None):
         r = int(counts[0])
         dl = template.data_len(r)
         row = np.zeros(61 + dl, dtype=np.uint8)
-        row[:61] = np.frombuffer(batch_header(0, dl, r), dtype=np.uint8)
+        row[:61] = np.frombuffer(batch_header(0, dl, r, last_delta=delta(max(r - 1, 0))), dtype=np.uint8)
         row[61:] = template.data[:dl]
         view = blob.reshape(len(counts), 61 + dl)
         view[:] = row
-        bo = (np.arange(len(counts), dtype=np.uint64) * np.uint64(r)).astype(">u8")
+        bo = (np.arange(len(counts), dtype=np.uint64) * np.uint64(delta(max(r - 1, 0)) + 1)).astype(">u8")
         view[:, :8] = bo.view(np.uint8).reshape(len(counts), 8)
         mask = np.zeros(61 + dl, dtype=bool)
         mask[61:] = template.mask[:dl]
@@ -171,13 +183,13 @@ def make_batches(shape: Shape, counts, seed: int, template: Template = None):
             r = int(r)
             dl = template.data_len(r)
             s = int(off[b])
-            blob[s:s + 61] = np.frombuffer(batch_header(base_offset, dl, r), dtype=np.uint8)
+            blob[s:s + 61] = np.frombuffer(batch_header(base_offset, dl, r, last_delta=delta(max(r - 1, 0))), dtype=np.uint8)
             seg = blob[s + 61:s + 61 + dl]
             seg[:] = template.data[:dl]
             idx = np.flatnonzero(template.mask[:dl])
             seg[idx] = splitmix64(seed, (len(idx) + 7) // 8, start=used).view(np.uint8)[:len(idx)]
             used += (len(idx) + 7) // 8
-            base_offset += r
+            base_offset += delta(max(r - 1, 0)) + 1
     n_records = int(counts.sum())
     return blob, off, n_records, n_records * shape.n_headers
 
@@ -270,12 +282,16 @@ def config(name: str, scale: float = 1.0):
         return None, np.full(max(1, int(8_192 * scale)), 1000), SEED_BASE + 6
     if name == "c3":   # large values: 1 MiB values, 4 records/batch
         return C3_SHAPE, np.full(max(1, int(256 * scale)), 4), SEED_BASE + 3
-    if name == "c5":   # ragged: records per batch log-uniform in [1, 10 000], 100 B values
+    if name in ("c5", "c5g"):   # ragged: records per batch log-uniform in [1, 10 000], 100 B values
+        # (c5g: the same batches after a compaction that took every third record: see DELTAS)
         n = max(1, int(4_096 * scale))
         u = splitmix64(SEED_BASE + 5, n).astype(np.float64) / 2.0 ** 64
         counts = np.floor(np.exp(u * np.log(10_000.0))).astype(np.int64).clip(1, 10_000)
         return C1_SHAPE, counts, SEED_BASE + 5
     raise ValueError(name)
+
+
+DELTAS = {"c5g": every_third_missing}   # workloads whose records are not numbered 0, 1, 2 ...: make_batches' `delta`
 
 
 def mixed_partitions(n_partitions: int, batches_each: int, seed: int = SEED_BASE + 4, only=None):

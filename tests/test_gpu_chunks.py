@@ -94,6 +94,113 @@ def test_chunks_that_do_not_join(codec):
     assert list(g["hdr_count"][:6]) == [3000 + 3 * 1000, 2000, 0, 0, 0, 0]
 
 
+def patched(codec, batches):
+    blob = np.frombuffer(b"".join(batches), dtype=np.uint8).copy()
+    off = offsets_of(batches)
+    crc_patch(codec, blob, off)
+    return blob, off
+
+
+def index_launches(codec, frame):
+    """One decode of `frame` (patched()) with every kernel timed, held to the oracle: (launches of
+    chunk_index_kernel, batches walked whole)."""
+    codec.profile(True)
+    check_against_oracle(codec, *frame)
+    launches = codec.kernel_times().get("chunk_index_kernel", (0, 0))[1]
+    codec.profile(False)
+    return launches, codec.last_walked_whole()
+
+
+def test_compacted_batches_chunk_by_chunk(codec):
+    """Batches that do not number their records 0, 1, 2 ... (what log compaction leaves: offset deltas
+    with gaps, a last_offset_delta that is not the record count less one) cannot take a chunk's first
+    record index from its offset delta: a launch ahead of the chunks' walk counts the records that start
+    in every chunk.  The call that first sees such a batch walks it whole (and says so to the calls that
+    follow on the context); from then on its chunks join up -- no batch is walked whole -- and the columns are
+    the sequential walk's, deltas that grow a byte at 64 and 8192 and all."""
+    rng = np.random.default_rng(21)
+    every_third = build_batch(dict(base_offset=0, last_offset_delta=synth.every_third_missing(9999)),
+                              records(10000, rng, od=synth.every_third_missing, ts=synth.every_third_missing))
+    tripled = build_batch(dict(base_offset=20000, last_offset_delta=3 * 3999),
+                          records(4000, rng, od=lambda i: 3 * i, headers=lambda i: 2))
+    # irregular gaps, and the batch's last records gone (last_offset_delta is the batch's as it was)
+    kept = np.sort(rng.choice(30000, 6000, replace=False))
+    irregular = build_batch(dict(base_offset=40000, last_offset_delta=31000),
+                            records(6000, rng, od=lambda i: int(kept[i]), ts=lambda i: 7 * int(kept[i]), headers=lambda i: 1))
+    # a numbered batch and small ones beside them
+    plain = build_batch(dict(base_offset=80000, last_offset_delta=4999), records(5000, rng))
+    small = [build_batch(dict(base_offset=90000 + 10 * i, last_offset_delta=9), records(10, rng)) for i in range(6)]
+    batches = small[:3] + [every_third, plain, tripled] + small[3:] + [irregular]
+    assert all(len(b) > 4 * CHUNK for b in (every_third, tripled, irregular))
+    frame, numbered = patched(codec, batches), patched(codec, [plain] + small)
+    fresh = hip.Codec(0)
+    try:
+        assert index_launches(fresh, frame) == (0, 0)       # (no chunk of theirs was guessed at: nothing to join)
+        assert index_launches(fresh, frame) == (1, 0)
+        # 256 calls without such a batch: the launch goes away again, and comes back
+        assert index_launches(fresh, numbered) == (1, 0)
+        d_blob, d_off = fresh.to_device(*numbered)
+        cols = hip.DeviceColumns(len(numbered[1]) - 1, 6000, 16, fresh.device)
+        for _ in range(256):
+            fresh.decode_dev(d_blob, len(numbered[0]), d_off, len(numbered[1]) - 1, cols)
+        assert index_launches(fresh, numbered) == (0, 0)
+        assert index_launches(fresh, frame) == (0, 0)
+        assert index_launches(fresh, frame) == (1, 0)
+    finally:
+        fresh.close()
+
+
+def test_compacted_batches_that_the_count_cannot_follow(codec):
+    """The count looks at a few places a chunk and takes records of one size to lie between them.  Where
+    that is not so -- sizes that change from record to record, one record of another size and then the old
+    size again, bytes behind the records -- the chunks do not join up (or are not counted at all) and the
+    batch is walked whole: same columns, and the context says how many such batches there were."""
+    import os
+    rng = np.random.default_rng(22)
+    gaps = lambda i: 2 * i + 1
+    changing = build_batch(dict(base_offset=0, last_offset_delta=gaps(3999)),
+                           records(4000, rng, od=gaps, value=lambda i: 90 + int(rng.integers(0, 30))))
+    one_off = build_batch(dict(base_offset=10000, last_offset_delta=gaps(3999)),
+                          records(4000, rng, od=gaps, value=lambda i: 101 if i in (700, 2500) else 100))
+    tail = bytearray(build_batch(dict(base_offset=20000, last_offset_delta=gaps(1999)), records(2000, rng, od=gaps)))
+    tail += bytes(rng.integers(0, 256, 3 * CHUNK, dtype=np.uint8))
+    tail[8:12] = struct.pack(">i", len(tail) - 12)
+    fine = build_batch(dict(base_offset=30000, last_offset_delta=gaps(3999)), records(4000, rng, od=gaps))
+    frame, fines = patched(codec, [changing, one_off, bytes(tail), fine]), patched(codec, [fine, fine])
+    os.environ["NISSHI_ADAPTIVE"] = "0"       # every launch in every call
+    try:
+        fresh = hip.Codec(0)
+    finally:
+        del os.environ["NISSHI_ADAPTIVE"]
+    try:
+        launches, whole = index_launches(fresh, frame)
+        assert launches == 1 and 1 <= whole <= 3
+        assert index_launches(fresh, fines) == (1, 0)
+    finally:
+        fresh.close()
+
+
+def test_c5_after_compaction_vs_oracle(codec):
+    """The ragged workload with every third record of every batch gone, through both schedules (chunks
+    beside the batches; a launch of their own), twice each so that the second call counts the chunks."""
+    import os
+    shape, blob, off, nr, nh, nb = __import__("tansu_amd.shard", fromlist=["x"]).make_shard("c5g", 0.012, 0)
+    crc_patch(codec, blob, off)
+    for beside in ("1", "0"):
+        os.environ["NISSHI_CHUNKS_BESIDE"] = beside
+        try:
+            other = hip.Codec(0)
+        finally:
+            del os.environ["NISSHI_CHUNKS_BESIDE"]
+        try:
+            for _ in range(2):
+                g, c, totals, *_ = check_against_oracle(other, blob, off)
+                assert (totals.n_records, totals.n_failed, totals.n_exact) == (nr, 0, 0)
+            assert other.last_walked_whole() == 0
+        finally:
+            other.close()
+
+
 def test_chunks_with_records_that_do_not_decode(codec):
     """A record whose length disagrees with its fields in chunk 2 (the reference takes
     the fields' word for it and goes on, record.rs:254-277), a record cut short by the
