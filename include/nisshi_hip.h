@@ -172,8 +172,10 @@ const char *nisshi_hip_last_error(const nisshi_hip_ctx *ctx);
  * decoded a wave a 64 KiB chunk on guesses that did not hold (see the decode,
  * below) and so were walked once more, whole, by one wave.  Same columns either
  * way; a number that stays high says the call's large batches are not what the
- * chunks' guesses expect.  (Not counted in calls of small batches, mean size
- * below NISSHI_WIDE_RING_FROM.)  No counterpart in the reference. */
+ * chunks' guesses expect.  (Counted only in calls of fewer than
+ * NISSHI_SEG_FEW_BATCHES batches of NISSHI_WIDE_RING_FROM bytes and more on
+ * average, where the chunks are worked on beside the batches.)  No counterpart
+ * in the reference. */
 uint64_t nisshi_hip_last_walked_whole(const nisshi_hip_ctx *ctx);
 
 /* Host-side framing of a records blob (de.rs:1056-1093): writes the start of

@@ -46,7 +46,7 @@ constexpr uint32_t kFlagExact = 1u;   // needs the sequential walk
 constexpr uint32_t kFlagMore = 2u;    // more headers than the slots it was expected to need: walked again
 constexpr uint32_t kFlagChunks = 8u;  // the batch's chunks are work items of chunk_kernel: its CRC comes from their residues
 constexpr uint32_t kFlagSeg = 4u;     // CRC and records chunk by chunk, a wave each (chunk_kernel); decode_fused_kernel checks that the chunks join up
-constexpr uint32_t kFlagGap = 16u;    // such a batch whose records are not numbered 0, 1, 2 ...: a chunk's first index comes from chunk_index_kernel
+constexpr uint32_t kFlagGap = 16u;    // such a batch whose records are not numbered 0, 1, 2 ...: a chunk's first index is the count of the records before it
 
 struct Work {
     uint32_t *alloc_count;  // record slots the batch gets
@@ -74,13 +74,12 @@ struct Work {
     uint64_t *tile_sum;     // the scans over very many batches: two sums a tile of kScanTile batches
     uint32_t *shape_guess;  // kShapeWords words a block of kSumBlock batches: the shape of the first record of the block's first batch (guess_shape)
     uint32_t *chunk_done;   // encode: the CRC work item has its residue already (from the copy of a long span); decode: the records
-                            // that start in the chunk, of batches whose chunks are counted first (chunk_index_kernel)
+                            // that start in the chunk under the call's tag, of batches whose chunks count them (kFlagGap)
     // Two words of page-locked host memory that the call leaves for the host's next call: [0] the entries
     // its list had, [1] the CRC work items its large batches have (or would have had).  May be NULL.
     uint32_t *hint;
 };
 
-constexpr uint32_t kModeChunks = 1u, kModeGaps = 2u, kModeShift = 2;  // batch_header_kernel's `mode`: the call's launches, and its number above them
 constexpr uint32_t kBigChunks = 8;        // from this many 64 KiB chunks on a batch's CRC is taken chunk by chunk
 constexpr uint32_t kSegChunks = 2;        // from this many on, a batch of small records may be decoded chunk by chunk too
 constexpr uint32_t kSegRecordMax = 1024;  // "small": the first record has at most this many bytes
@@ -151,7 +150,7 @@ __device__ inline uint64_t block_exclusive_scan64(uint64_t v, uint64_t *lds, uin
 // it is expected to need (high half).
 __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t *batch_off, uint32_t b, int by_value,
                                             const nisshi_columns &c, const Work &w, uint32_t count_small,
-                                            uint32_t seg_chunks, uint32_t mode, uint32_t &chunk_items) {
+                                            uint32_t seg_chunks, bool chunks_on, uint32_t &chunk_items) {
     const uint8_t *p = blob + batch_off[b];
     uint64_t len = batch_off[b + 1] - batch_off[b];
     int st = NISSHI_OK;
@@ -309,17 +308,13 @@ __device__ inline uint64_t batch_header_one(const uint8_t *blob, const uint64_t 
     // from one wave.  Either way its chunks are work items.
     bool segmented = fits && chunks >= seg_chunks && first_size != 0 && first_size <= kSegRecordMax;
     // A batch that does not number its records 0, 1, 2 ... (a compacted one: last_offset_delta + 1 is not
-    // its record count) has its chunks' first indices counted by a launch of its own, chunk_index_kernel,
-    // which a call has when the call before it saw such a batch (kModeGaps): the call's number is left
-    // where the host finds it.  Without that launch the batch is one wave's.
+    // its record count): its chunks' waves count their records before they walk them.
     bool gapped = segmented && (uint32_t)lod + 1 != record_count;
-    if (gapped && w.hint != nullptr) w.hint[3] = mode >> kModeShift;
-    bool by_chunk = segmented && (!gapped || (mode & kModeGaps));
-    // (kModeChunks not set: the call has no launch that works on chunks -- the call before it had no such
+    // (chunks_on false: the call has no launch that works on chunks -- the call before it had no such
     // batch; the items are still counted, for the call after this one, and the batch is one wave's)
     chunk_items = segmented || chunks >= kBigChunks ? chunks : 0;
-    if (chunk_items && (mode & kModeChunks))
-        w.flags[b] |= !by_chunk ? kFlagChunks : gapped ? kFlagSeg | kFlagChunks | kFlagGap : kFlagSeg | kFlagChunks;
+    if (chunk_items && chunks_on)
+        w.flags[b] |= !segmented ? kFlagChunks : gapped ? kFlagSeg | kFlagChunks | kFlagGap : kFlagSeg | kFlagChunks;
     w.hdr_need[b] = 0;
     return ((uint64_t)expect << 32) | (fits ? record_count : 0u);
 }
@@ -330,7 +325,7 @@ __device__ inline void guess_shape(const uint8_t *blob, const uint64_t *batch_of
 // there) each leave a guess at the shape of their block's records: guess_shape.
 __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
                                     int by_value, nisshi_columns c, Work w, uint32_t count_small, uint32_t seg_chunks,
-                                    uint32_t mode) {
+                                    uint32_t chunks_on) {
     __shared__ uint64_t wave_sums[kSumBlock >> 6];
     uint32_t n_blocks = (n + kSumBlock - 1) / kSumBlock;
     if (blockIdx.x >= n_blocks) {
@@ -342,7 +337,7 @@ __global__ __launch_bounds__(kSumBlock) void batch_header_kernel(const uint8_t *
     if (b < 8) w.totals[b] = 0;
     uint64_t mine = 0;  // record slots in the low half, expected header slots in the high half
     uint32_t items = 0;  // CRC work items: those of large batches
-    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, seg_chunks, mode, items);
+    if (b < n) mine = batch_header_one(blob, batch_off, b, by_value, c, w, count_small, seg_chunks, chunks_on != 0, items);
     uint64_t total;
     uint64_t before = block_exclusive_scan64(mine, wave_sums, total);
     if (b < n) {
@@ -2208,11 +2203,10 @@ __device__ __forceinline__ bool find_record_start(const View &ring, uint32_t bia
 }
 
 // ---- the first record index of every chunk of a batch that does not number its
-// records 0, 1, 2 ... (kFlagGap): counted ahead of the chunks' walk, a wave a chunk.
+// records 0, 1, 2 ... (kFlagGap)
 //
-// The wave finds the chunk's first record as the chunk's walk will (find_record_start
-// over the batch in memory) and counts the records that start in the chunk without
-// walking them: records of one size S lie S bytes apart, so the lanes look at 64
+// The chunk's wave counts the records that start in its chunk without walking them
+// (records_from): records of one size S lie S bytes apart, so the lanes look at 64
 // places at once -- is there a record of S bytes at start + i S? -- spread over the
 // chunk; where one is not, the places between it and the last that was are looked at
 // the same way until the first record of another size is known, and the count goes
@@ -2221,8 +2215,11 @@ __device__ __forceinline__ bool find_record_start(const View &ring, uint32_t bia
 // chunk's start is, and segments_join checks both -- a chunk's walk ends at the
 // record index that the next one started with only if every count before was right.
 // A chunk whose sizes change more often than kIndexTries times is not counted
-// (kSegFailed: the batch is then one wave's).
+// (the batch is then one wave's).  The wave leaves its count for the waves of the
+// chunks behind it and adds up those of the chunks before it (decode_unit).
 constexpr int kIndexTries = 16;
+constexpr uint32_t kCountFailed = 0xffffu;  // a chunk's count as it is left for the chunks behind it: sixteen bits under the call's tag
+constexpr uint64_t kIndexWait = 50000;      // how long a chunk's wave waits for the counts before it: 500 us of the 100 MHz clock
 
 // The batch in memory.  A read keeps the 32 bytes around it in registers: the head
 // of a record -- its length, attributes and deltas -- is then one trip to memory.
@@ -2248,70 +2245,18 @@ struct MemoryView {
     }
 };
 
-// A stretch of the batch copied to LDS, kIndexStretch bytes from byte `origin` on
-// (a multiple of 16): what find_record_start reads around a chunk's first byte.
-constexpr uint32_t kIndexStretch = 5 * kWave * 16;
-static_assert(kIndexStretch >= kSegScanBytes + 3 * kSegRecordMax + 80 + 16 + 32, "the scan, three records behind it, a record's head");
-struct StretchView {
-    const lds_u32 *buf;
-    uint32_t origin;
-    __device__ __forceinline__ uint64_t read64(uint32_t at) const {
-        uint32_t o = at - origin;
-        o = o < kIndexStretch ? o : 0u;  // (positions of lanes that are not looked at)
-        const lds_u32 *p = buf + (o >> 2);
-        uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-        uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3);
-        uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3);
-        return ((uint64_t)hi << 32) | lo;
-    }
-};
-
-// The records that start in chunk `chunk` of batch b (kSegFailed: not counted).
-// buf: kIndexStretch + 16 bytes of LDS of the wave's own.
-__device__ __forceinline__ uint32_t chunk_record_count(const uint8_t *blob, const uint64_t *batch_off, uint32_t b, uint32_t chunk,
-                                                       uint32_t chunks, const nisshi_columns &c, lds_u32 *buf, int lane) {
-    // (everything that b alone gives is asked for at once)
-    uint64_t off_v = batch_off[b];
-    uint32_t length_v = (uint32_t)c.batch_length[b], data_len_v = c.data_len[b], count_v = c.record_count[b];
-    uint32_t lod_v = (uint32_t)c.last_offset_delta[b];
-    uint64_t lo = (((uint64_t)uni((uint32_t)(off_v >> 32)) << 32) | uni((uint32_t)off_v)) + 21, hi = lo + uni(length_v) - 9;
-    uint32_t data_len = uni(data_len_v), count = uni(count_v), lod = uni(lod_v);
-    uint64_t grid = lo & ~uint64_t(15);
-    MemoryView view(blob + grid, (((uint32_t)(hi - grid) - 1) & ~15u) + 16);
-    uint32_t bias = 40 + (uint32_t)(lo - grid);
-    uint32_t row0 = chunk * kChunkRows;
-    uint32_t x = chunk ? row0 * kRowBytes - bias : 0;
-    uint32_t pos_end = chunk + 1 < chunks ? (row0 + kChunkRows) * kRowBytes - bias : data_len;
-    pos_end = pos_end < data_len ? pos_end : data_len;
-    uint32_t pos = 0, unused;
-    if (x >= data_len) return 0;
-    StretchView near{buf, 0xffffffffu};
-    if (chunk) {
-        uint32_t origin = (x + bias) & ~15u;
-        u32x4 rows[5];
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-            uint32_t at = origin + (uint32_t)(j * kWave + lane) * 16;
-            rows[j] = at + 16 <= view.limit ? *reinterpret_cast<const u32x4 *>(view.grid + at) : u32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int j = 0; j < 5; j++) *(lds_u128 *)(buf + (j * kWave + lane) * 4) = rows[j];
-        if (lane < 4) buf[kIndexStretch / 4 + lane] = 0;
-        lds_order();
-        near.origin = origin;
-        if (!find_record_start(near, bias, x, data_len, count, lane, pos, unused, true, lod)) return 0;
-    }
-    pos = uni(pos);
+// The records that start in [pos, pos_end) of the record data, the first of them at
+// pos (kSegFailed: not counted).
+__device__ __forceinline__ uint32_t records_from(const MemoryView &view, uint32_t bias, uint32_t pos, uint32_t pos_end,
+                                                 uint32_t data_len, int lane) {
     uint32_t counted = 0;
     for (int tries = 0; tries < kIndexTries; tries++) {
         if (pos >= pos_end) return counted;
         uint32_t size;
         int32_t od;
-        bool held = chunk && pos + bias - near.origin + 32 <= kIndexStretch;  // (the chunk's first record is)
-        if (!(held ? plausible_record(near, bias, pos, data_len, size, od) : plausible_record(view, bias, pos, data_len, size, od)))
-            return kSegFailed;
+        if (!plausible_record(view, bias, pos, data_len, size, od)) return kSegFailed;
         size = uni(size);
-        // records 0 .. m - 1 of this size from pos on start before the chunk's end; record 0 is there
+        // records 0 .. m - 1 of this size from pos on start before the end; record 0 is there
         uint32_t m = (pos_end - pos + size - 1) / size, good_to = 0, bad_at = m;
         while (bad_at - good_to > 1) {
             uint32_t between = bad_at - good_to - 1, step = (between + kWave - 1) / kWave;
@@ -2455,7 +2400,7 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
                                             const uint64_t *batch_off, uint32_t n, const nisshi_columns &c, const Work &w,
                                             uint64_t rec_cap, uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed,
                                             const uint64_t *before, uint32_t *ring, uint32_t *shape_tab, int lane,
-                                            uint32_t phase = kPhaseAll) {
+                                            uint32_t phase = kPhaseAll, uint32_t tag = 0) {
 #ifdef NISSHI_PHASES
     uint64_t tl[6];
     uint64_t wall0 = wall_clock64();
@@ -2505,9 +2450,10 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         uint32_t v = crc_combine_wave(batch_off, c.batch_length, b, chunks, w.partial + first_item, t, lane);
         if (lane == 0) c.crc_computed[b] = v;
         joined_up = (flags & kFlagSeg) && status == NISSHI_OK && segments_join(w, first_item, chunks, count, lane, &sized);
-        // (counted: batches whose chunks did not join up, walked whole below; not by the kernel of
-        // small batches, which has no register to spare)
-        if (kRows != 8 && (flags & kFlagSeg) && status == NISSHI_OK && !joined_up && lane == 0)
+        // (counted: batches whose chunks did not join up, walked whole below; only by the launch behind
+        // chunks that were worked on beside the batches -- the kernels that take every batch of a call
+        // slow down by 3 % with one more thing to do, rare as it is)
+        if (phase == kPhaseAfter && (flags & kFlagSeg) && status == NISSHI_OK && !joined_up && lane == 0)
             atomicAdd(reinterpret_cast<unsigned long long *>(w.totals + 5), 1ull);
 #ifdef NISSHI_DIAG_JOINS  // diagnostic builds only: batches whose chunks did not join up, counted as sequential walks
         if ((flags & kFlagSeg) && !joined_up && lane == 0) {
@@ -2596,11 +2542,11 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
     // ---- where the unit's walk starts and ends
     uint32_t k0 = 0, pos0 = 0, pos_end = 0xffffffffu, hdr_first = hdr_base, hdr_slots = expect;
     bool none = false;  // seg: no record starts in the chunk
-    if (seg && do_walk) {
+    bool gapped = seg && (flags & kFlagGap) != 0;
+    if (seg && (do_walk || gapped)) {
         lds_order();
-        bool gapped = (flags & kFlagGap) != 0;
-        if (chunk) {
-            uint32_t data_len = uni(c.data_len[b]);
+        uint32_t data_len = uni(c.data_len[b]);
+        if (chunk && do_walk) {
             uint32_t lod = gapped ? uni((uint32_t)c.last_offset_delta[b]) : 0u;
             do_walk = x < data_len &&
                       find_record_start(RingView<kRows>{stream.ring}, bias, x, data_len, count, lane, pos0, k0, gapped, lod);
@@ -2608,24 +2554,50 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
         }
         pos0 = uni(pos0);
         k0 = uni(k0);
-        if (gapped && chunk) {
-            // the records of the chunks before this one, as chunk_index_kernel counted them
+        if (chunk + 1 < chunks) pos_end = fold_to * kRowBytes - bias;
+        if (gapped) {
+            // A batch that does not number its records 0, 1, 2 ...: the chunk's first index
+            // is the number of records that start in the chunks before it.  Every chunk's
+            // wave counts its own (records_from) and leaves the count, under the call's tag,
+            // for the waves of the chunks behind it, before it waits for those of the chunks
+            // before it -- which are further on than itself: their workgroups come first in
+            // the grid.  (A wave that waits in vain, kIndexWait, gives up: the chunks then
+            // do not join up and the batch is walked whole.)
+            uint32_t here = kCountFailed;
+            if (none) here = 0;
+            if (do_walk) {
+                MemoryView view(stream.lane_ptr - (uint32_t)lane * 16, ((stream.hi - 1) & ~15u) + 16);
+                uint32_t to = pos_end < data_len ? pos_end : data_len;
+                uint32_t n_here = records_from(view, bias, pos0, to, data_len, lane);
+                here = n_here < kCountFailed ? n_here : kCountFailed;
+            }
+            if (lane == 0)
+                __hip_atomic_store(w.chunk_done + mine, (tag << 16) | here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t sum = 0;
-            bool known = true;
-            for (uint32_t j = (uint32_t)lane; j < chunk; j += kWave) {
-                uint32_t v = w.chunk_done[mine - chunk + j];
-                known = known && v != kSegFailed;
-                sum += v;
+            bool known = do_walk || none;
+            for (uint32_t j0 = 0; known && j0 < chunk; j0 += kWave) {
+                uint32_t j = j0 + (uint32_t)lane, v = 0;
+                uint64_t since = wall_clock64();
+                for (;;) {
+                    if (j < chunk) v = __hip_atomic_load(w.chunk_done + (mine - chunk + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(j >= chunk || (v >> 16) == tag)) break;
+                    if (wall_clock64() - since > kIndexWait) {
+                        v = kCountFailed;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                known = __all(j >= chunk || (v & 0xffffu) != kCountFailed);
+                sum += j < chunk ? v & 0xffffu : 0u;
             }
             for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
             k0 = uni(sum);
-            if (!__all(known)) do_walk = none = false;  // (kSegFailed below)
+            if (!known) do_walk = none = false;  // (kSegFailed below)
         }
         // every record is taken to have the header count of the batch's first: the chunk's headers start k0 such records in
         uint32_t hc = count ? expect / count : 0;
         hdr_first += k0 * hc;
         hdr_slots -= k0 * hc;
-        if (chunk + 1 < chunks) pos_end = fold_to * kRowBytes - bias;
     }
     uint32_t k = k0, pos = pos0;
     bool joined = false;  // seg: the chunk's records are decoded, as far as the chunk can tell
@@ -2720,7 +2692,7 @@ __device__ __forceinline__ void leave_hints(const Work &w, uint32_t n, bool pref
 template <int kRows>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void chunk_kernel(
     const uint8_t *blob, const uint64_t *batch_off, uint32_t n, nisshi_columns c, Work w, uint64_t rec_cap,
-    uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed, const uint64_t *before) {
+    uint64_t hdr_cap, const CrcTables *t, uint32_t prefixed, const uint64_t *before, uint32_t tag) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[RingCfg<kRows>::kRingWords];
     __shared__ __attribute__((aligned(16))) uint32_t shape_tab[kShapeWords];
     int lane = threadIdx.x & 63;
@@ -2731,30 +2703,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         items.locate(w, item, lane, b, chunk);
         if (uni(w.flags[b]) & kFlagSeg)
             decode_unit<kRows>(true, b, chunk, item, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before, ring,
-                               shape_tab, lane);
+                               shape_tab, lane, kPhaseAll, tag);
         else
             crc_chunk_one(item, b, chunk, blob, batch_off, c.batch_length, c.crc_computed, w, t, lane);
-    }
-}
-
-// The chunks of batches that do not number their records 0, 1, 2 ..., a wave each
-// (as many passes as the grid needs), ahead of the launch that walks the chunks:
-// how many records start in the chunk (chunk_record_count), from which the chunk's
-// wave has the index of its first record.
-__global__ __launch_bounds__(64) void chunk_index_kernel(const uint8_t *blob, const uint64_t *batch_off, uint32_t n,
-                                                         nisshi_columns c, Work w, uint32_t prefixed) {
-    __shared__ __attribute__((aligned(16))) uint32_t stretch[kIndexStretch / 4 + 4];
-    int lane = threadIdx.x & 63;
-    ChunkItems items;
-    items.init(w, n, prefixed != 0, lane);
-    for (uint32_t item = blockIdx.x; item < items.total; item += gridDim.x) {
-        uint32_t b, chunk;
-        items.locate(w, item, lane, b, chunk);
-        uint32_t flags_v = w.flags[b], chunks_v = w.n_chunks[b];
-        if (!(uni(flags_v) & kFlagGap)) continue;
-        uint32_t counted = chunk_record_count(blob, batch_off, b, chunk, uni(chunks_v), c, (lds_u32 *)stretch, lane);
-        if (lane == 0) w.chunk_done[item] = counted;
-        lds_order();
     }
 }
 
@@ -2776,6 +2727,9 @@ __device__ __forceinline__ void fused_body(const uint8_t *blob, const uint64_t *
     int lane = threadIdx.x & 63;
     uint32_t wave = uni(threadIdx.x >> 6);
     static_assert(kPhase == kPhaseAll || kPack == 1, "chunks beside batches: a wave a workgroup");
+    // (chunks beside batches: the call's tag for the chunks' counts rides above the number of their workgroups)
+    uint32_t tag = kPhase == kPhaseBeside ? chunk_groups >> 16 : 0u;
+    if (kPhase == kPhaseBeside) chunk_groups &= 0xffffu;
     if (kPhase == kPhaseBeside && blockIdx.x < chunk_groups) {
         // The chunks of large batches are the largest units of work and start first,
         // the batches fill the machine up behind them.
@@ -2786,7 +2740,7 @@ __device__ __forceinline__ void fused_body(const uint8_t *blob, const uint64_t *
             items.locate(w, item, lane, cb, chunk);
             if (uni(w.flags[cb]) & kFlagSeg)
                 decode_unit<kRows>(true, cb, chunk, item, blob, batch_off, n, c, w, rec_cap, hdr_cap, t, prefixed, before,
-                                   rings[0], shape_tabs[0], lane);
+                                   rings[0], shape_tabs[0], lane, kPhaseAll, tag);
             else
                 crc_chunk_one(item, cb, chunk, blob, batch_off, c.batch_length, c.crc_computed, w, t, lane);
         }

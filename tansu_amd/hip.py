@@ -128,8 +128,9 @@ def load() -> ctypes.CDLL:
     lib.nisshi_hip_status_str.restype = ctypes.c_char_p
     lib.nisshi_hip_last_error.argtypes = [vp]
     lib.nisshi_hip_last_error.restype = ctypes.c_char_p
-    lib.nisshi_hip_last_walked_whole.argtypes = [vp]
-    lib.nisshi_hip_last_walked_whole.restype = ctypes.c_uint64
+    if ABI_VERSION is not None or hasattr(lib, "nisshi_hip_last_walked_whole"):   # (tools load older builds to compare)
+        lib.nisshi_hip_last_walked_whole.argtypes = [vp]
+        lib.nisshi_hip_last_walked_whole.restype = ctypes.c_uint64
     lib.nisshi_frame_split.argtypes = [vp, u64, vp, u64, ctypes.POINTER(u64)]
     lib.nisshi_records_prefix_decode.argtypes = [vp, u64, i32, ctypes.POINTER(u64),
                                                  ctypes.POINTER(u32), ctypes.POINTER(i32)]

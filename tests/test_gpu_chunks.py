@@ -61,10 +61,11 @@ def test_chunks_join(codec):
 
 
 def test_chunks_that_do_not_join(codec):
-    """What the guesses cannot know: a header count that changes inside the batch, offset
-    deltas with gaps (a compacted batch), bytes inside a value that look like a run of
-    records right where a chunk begins, records that end well before the batch does, and
-    a record count below the records present.  The walk of the whole batch decides."""
+    """What the guesses cannot know: a header count that changes inside the batch, bytes
+    inside a value that look like a run of records right where a chunk begins, records that
+    end well before the batch does, and a record count below the records present.  The walk
+    of the whole batch decides.  (Offset deltas with gaps, a compacted batch, are among them
+    too: its chunks count their records instead, see below.)"""
     rng = np.random.default_rng(2)
     more_headers = build_batch(dict(base_offset=0, last_offset_delta=3999),
                                records(4000, rng, headers=lambda i: 1 if i < 3000 else 3))
@@ -101,23 +102,20 @@ def patched(codec, batches):
     return blob, off
 
 
-def index_launches(codec, frame):
-    """One decode of `frame` (patched()) with every kernel timed, held to the oracle: (launches of
-    chunk_index_kernel, batches walked whole)."""
-    codec.profile(True)
+def walked_whole(codec, frame):
+    """One decode of `frame` (patched()), held to the oracle: the batches whose chunks did not join up."""
     check_against_oracle(codec, *frame)
-    launches = codec.kernel_times().get("chunk_index_kernel", (0, 0))[1]
-    codec.profile(False)
-    return launches, codec.last_walked_whole()
+    return codec.last_walked_whole()
 
 
 def test_compacted_batches_chunk_by_chunk(codec):
     """Batches that do not number their records 0, 1, 2 ... (what log compaction leaves: offset deltas
     with gaps, a last_offset_delta that is not the record count less one) cannot take a chunk's first
-    record index from its offset delta: a launch ahead of the chunks' walk counts the records that start
-    in every chunk.  The call that first sees such a batch walks it whole (and says so to the calls that
-    follow on the context); from then on its chunks join up -- no batch is walked whole -- and the columns are
-    the sequential walk's, deltas that grow a byte at 64 and 8192 and all."""
+    record index from its offset delta: every chunk's wave counts the records that start in its chunk
+    and adds up the counts of the chunks before it.  The chunks join up -- no batch is walked whole --
+    and the columns are the sequential walk's, deltas that grow a byte at 64 and 8192 and all; whichever
+    launch works on the chunks."""
+    import os
     rng = np.random.default_rng(21)
     every_third = build_batch(dict(base_offset=0, last_offset_delta=synth.every_third_missing(9999)),
                               records(10000, rng, od=synth.every_third_missing, ts=synth.every_third_missing))
@@ -132,22 +130,19 @@ def test_compacted_batches_chunk_by_chunk(codec):
     small = [build_batch(dict(base_offset=90000 + 10 * i, last_offset_delta=9), records(10, rng)) for i in range(6)]
     batches = small[:3] + [every_third, plain, tripled] + small[3:] + [irregular]
     assert all(len(b) > 4 * CHUNK for b in (every_third, tripled, irregular))
-    frame, numbered = patched(codec, batches), patched(codec, [plain] + small)
-    fresh = hip.Codec(0)
-    try:
-        assert index_launches(fresh, frame) == (0, 0)       # (no chunk of theirs was guessed at: nothing to join)
-        assert index_launches(fresh, frame) == (1, 0)
-        # 256 calls without such a batch: the launch goes away again, and comes back
-        assert index_launches(fresh, numbered) == (1, 0)
-        d_blob, d_off = fresh.to_device(*numbered)
-        cols = hip.DeviceColumns(len(numbered[1]) - 1, 6000, 16, fresh.device)
-        for _ in range(256):
-            fresh.decode_dev(d_blob, len(numbered[0]), d_off, len(numbered[1]) - 1, cols)
-        assert index_launches(fresh, numbered) == (0, 0)
-        assert index_launches(fresh, frame) == (0, 0)
-        assert index_launches(fresh, frame) == (1, 0)
-    finally:
-        fresh.close()
+    frame = patched(codec, batches)
+    for beside in ("1", "0"):
+        os.environ["NISSHI_CHUNKS_BESIDE"] = beside
+        os.environ["NISSHI_ADAPTIVE"] = "0"       # every launch in every call
+        try:
+            fresh = hip.Codec(0)
+        finally:
+            del os.environ["NISSHI_CHUNKS_BESIDE"], os.environ["NISSHI_ADAPTIVE"]
+        try:
+            assert walked_whole(fresh, frame) == 0
+            assert walked_whole(fresh, frame) == 0      # (the counts an earlier call left are not this call's)
+        finally:
+            fresh.close()
 
 
 def test_compacted_batches_that_the_count_cannot_follow(codec):
@@ -155,7 +150,6 @@ def test_compacted_batches_that_the_count_cannot_follow(codec):
     that is not so -- sizes that change from record to record, one record of another size and then the old
     size again, bytes behind the records -- the chunks do not join up (or are not counted at all) and the
     batch is walked whole: same columns, and the context says how many such batches there were."""
-    import os
     rng = np.random.default_rng(22)
     gaps = lambda i: 2 * i + 1
     changing = build_batch(dict(base_offset=0, last_offset_delta=gaps(3999)),
@@ -167,22 +161,17 @@ def test_compacted_batches_that_the_count_cannot_follow(codec):
     tail[8:12] = struct.pack(">i", len(tail) - 12)
     fine = build_batch(dict(base_offset=30000, last_offset_delta=gaps(3999)), records(4000, rng, od=gaps))
     frame, fines = patched(codec, [changing, one_off, bytes(tail), fine]), patched(codec, [fine, fine])
-    os.environ["NISSHI_ADAPTIVE"] = "0"       # every launch in every call
+    fresh = hip.Codec(0)
     try:
-        fresh = hip.Codec(0)
-    finally:
-        del os.environ["NISSHI_ADAPTIVE"]
-    try:
-        launches, whole = index_launches(fresh, frame)
-        assert launches == 1 and 1 <= whole <= 3
-        assert index_launches(fresh, fines) == (1, 0)
+        assert 1 <= walked_whole(fresh, frame) <= 3
+        assert walked_whole(fresh, fines) == 0
     finally:
         fresh.close()
 
 
 def test_c5_after_compaction_vs_oracle(codec):
     """The ragged workload with every third record of every batch gone, through both schedules (chunks
-    beside the batches; a launch of their own), twice each so that the second call counts the chunks."""
+    beside the batches; a launch of their own), twice each."""
     import os
     shape, blob, off, nr, nh, nb = __import__("tansu_amd.shard", fromlist=["x"]).make_shard("c5g", 0.012, 0)
     crc_patch(codec, blob, off)
