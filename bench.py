@@ -228,7 +228,7 @@ def main():
                          "c4": "C4: mixed topic-partitions (five shapes by p mod 5, 64 batches each), 128 a GPU",
                          "c5": "C5: ragged batches, 1-10k records of 100 B, as ProduceRequest v11 partition data "
                                "(1-8 partitions a request, 1-4 batches a records field)",
-                         "c5g": "C5 after a compaction that took every third record of every batch (offset deltas "
+                         "c5g": "C5g: C5 after a compaction that took every third record of every batch (offset deltas "
                                 "0, 1, 3, 4, 6, ...), as ProduceRequest v11 partition data"}[args.workload],
             "batches_per_gpu": n_batches,
             "records_per_gpu": n_records,

@@ -145,6 +145,32 @@ def test_compacted_batches_chunk_by_chunk(codec):
             fresh.close()
 
 
+def test_what_compaction_itself_leaves(codec):
+    """A partition of large batches through the library's own compaction (nisshi_hip_compact: the last
+    record of every key stays), and the batches it rewrote decoded again: gaps wherever a key came again
+    later, the batch's last_offset_delta as it was.  Their chunks join up."""
+    rng = np.random.default_rng(23)
+    batches, base = [], 0
+    for b in range(4):
+        n = 7000
+        keys = rng.integers(0, 14000, n)
+        batches.append(build_batch(dict(base_offset=base, last_offset_delta=n - 1),
+                                   records(n, rng, value=lambda i: 100, key=lambda i: b"key-%08d" % keys[i])))
+        base += n
+    blob, off = patched(codec, batches)
+    pieces, removed, action, status, totals = codec.compact(blob.tobytes(), off)
+    st, want_removed, want_action, want_pieces = oracle.compact_partition([blob[int(off[i]):int(off[i + 1])].tobytes()
+                                                                          for i in range(4)])
+    assert st == C.OK and pieces == want_pieces and list(action) == [1, 1, 1, 1]
+    assert all(1000 < r < 6000 for r in removed)
+    assert all(len(p) > 2 * CHUNK + 4096 for p in pieces)
+    fresh = hip.Codec(0)
+    try:
+        assert walked_whole(fresh, patched(codec, pieces)) == 0
+    finally:
+        fresh.close()
+
+
 def test_compacted_batches_that_the_count_cannot_follow(codec):
     """The count looks at a few places a chunk and takes records of one size to lie between them.  Where
     that is not so -- sizes that change from record to record, one record of another size and then the old

@@ -4,6 +4,6 @@
 set -e
 out=$1
 : > $out
-for w in c1 c2 c2v c3 c4 c5; do
+for w in c1 c2 c2v c3 c4 c5 c5g; do
     timeout -k 10 200 python3 bench.py --workload $w --no-cpu-baseline --steps 30 >> $out
 done

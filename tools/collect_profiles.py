@@ -9,7 +9,7 @@ usage: python tools/collect_profiles.py <round tag> [workload ...]"""
 import glob, json, os, re, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-workloads = sys.argv[2:] or ["c1", "c2", "c2v", "c3", "c4", "c5"]
+workloads = sys.argv[2:] or ["c1", "c2", "c2v", "c3", "c4", "c5", "c5g"]
 dst = os.path.join(root, "profiles")
 tpath = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}

@@ -4,7 +4,7 @@ import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 traffic = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-keys = ["c1", "c2", "c2v", "c3", "c4", "c5"]
+keys = ["c1", "c2", "c2v", "c3", "c4", "c5", "c5g"]
 print("| Workload | decode step | records/s | dominant kernel: ms, fraction of 8 TB/s | HBM traffic / algorithmic | re-encode (bit-exact) |")
 print("|---|---|---|---|---|---|")
 for key, line in zip(keys, open(os.path.join(root, "profiles", f"{tag}_all_configs.jsonl"))):
