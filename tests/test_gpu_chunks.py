@@ -171,6 +171,40 @@ def test_what_compaction_itself_leaves(codec):
         fresh.close()
 
 
+def test_compacted_batches_through_the_other_entry_points(codec):
+    """A compacted batch of sixteen chunks among seven thousand small batches (a call of that many has
+    its chunks worked on by a launch of their own, from the second call on: the first leaves word of
+    them); the same frame through the host-buffer entry point, and through the one that allocates
+    nothing.  All against the checker."""
+    from util import assert_same
+    rng = np.random.default_rng(24)
+    big = build_batch(dict(base_offset=0, last_offset_delta=synth.every_third_missing(9999) + 5),
+                      records(10000, rng, od=synth.every_third_missing, ts=lambda i: 2 * i, headers=lambda i: 1))
+    small = build_batch(dict(base_offset=50000, last_offset_delta=4), records(5, rng, od=lambda i: i))
+    assert len(big) > 16 * CHUNK
+    blob, off = patched(codec, [small] * 3500 + [big] + [small] * 3500)
+    st, want, nr, nh = oracle.decode_columns(blob, off)
+    assert st == C.OK
+    fresh = hip.Codec(0)
+    try:
+        d_blob, d_off = fresh.to_device(blob, off)
+        n_b = len(off) - 1
+        for call in range(3):
+            cols = hip.DeviceColumns(n_b, nr, nh, fresh.device)
+            fresh.profile(True)
+            totals = fresh.decode_dev(d_blob, len(blob), d_off, n_b, cols, static=call == 2)
+            launched = "chunk_kernel" in fresh.kernel_times()
+            fresh.profile(False)
+            assert launched == (call == 1)      # (the entry point that allocates nothing records no events)
+            assert (totals.n_records, totals.n_headers, totals.n_failed) == (nr, nh, 0)
+            assert_same(cols.to_host(nr, nh), want, n_b)
+        got, totals = fresh.decode(blob.tobytes(), off)
+        assert (totals.n_records, totals.n_headers, totals.n_failed) == (nr, nh, 0)
+        assert_same(got, want, n_b)
+    finally:
+        fresh.close()
+
+
 def test_compacted_batches_that_the_count_cannot_follow(codec):
     """The count looks at a few places a chunk and takes records of one size to lie between them.  Where
     that is not so -- sizes that change from record to record, one record of another size and then the old
