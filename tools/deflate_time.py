@@ -1,6 +1,7 @@
-"""Time and ratio of the LZ4 deflate: the batch of tools/inflate_time.py (a thousand small records: keys, values
-of words, two headers) repeated COUNT times (8192 by default), compressed on the device; liblz4 (pyarrow's) on the
-same record data for the ratio.  python tools/deflate_time.py [COUNT]"""
+"""Time and ratio of the deflate (CODEC=lz4, the default, or gzip in the environment): the batch of
+tools/inflate_time.py (a thousand small records: keys, values of words, two headers) repeated COUNT times (8192 by
+default), compressed on the device; liblz4 (pyarrow's) or zlib on the same record data for the ratio.
+python tools/deflate_time.py [COUNT]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -22,8 +23,9 @@ blob = np.frombuffer(plain * count, dtype=np.uint8)
 off = np.arange(count + 1, dtype=np.uint64) * len(plain)
 codec = hip.Codec(0)
 d_blob, d_off = codec.to_device(blob, off)
-d_codec = torch.full((count,), 3, dtype=torch.uint8, device=codec.device)
-res = {"batches": count, "plain_bytes": len(blob)}
+which = os.environ.get("CODEC", "lz4")
+d_codec = torch.full((count,), {"lz4": 3, "gzip": 1}[which], dtype=torch.uint8, device=codec.device)
+res = {"codec": which, "batches": count, "plain_bytes": len(blob)}
 for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -34,11 +36,16 @@ assert totals.n_failed == 0
 res["compressed_bytes"] = int(totals.out_bytes)
 res["ratio"] = round(totals.out_bytes / len(blob), 3)
 res["call_gbs_in"] = round(len(blob) / res["call_ms"] / 1e6, 1)
-try:
-    import pyarrow as pa
-    res["liblz4_ratio"] = round((61 + len(pa.compress(plain[61:], codec="lz4", asbytes=True))) / len(plain), 3)
-except Exception as e:  # noqa: BLE001
-    res["liblz4_ratio"] = str(e)
+if which == "gzip":
+    import zlib
+    for level in (1, 6):
+        res[f"zlib_level{level}_ratio"] = round((61 + 18 + len(zlib.compress(plain[61:], level)) - 6) / len(plain), 3)
+else:
+    try:
+        import pyarrow as pa
+        res["liblz4_ratio"] = round((61 + len(pa.compress(plain[61:], codec="lz4", asbytes=True))) / len(plain), 3)
+    except Exception as e:  # noqa: BLE001
+        res["liblz4_ratio"] = str(e)
 # what came out inflates to what went in
 back, back_off, st, t3 = codec.inflate_dev(d_out, totals.out_bytes, d_out_off, count)
 got = back[:t3.out_bytes].cpu().numpy()

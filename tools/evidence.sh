@@ -18,4 +18,5 @@ for c in snappy lz4 gzip zstd; do
   CODEC=$c timeout -k 10 300 python3 tools/inflate_time.py > $o/${tag}_inflate_$c.json 2> $o/${tag}_inflate_$c.err
 done
 timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate.json 2> $o/${tag}_deflate.err
+CODEC=gzip timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate_gzip.json 2> $o/${tag}_deflate_gzip.err
 echo "inflate and deflate done"
