@@ -585,17 +585,20 @@ int nisshi_hip_inflate(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_l
 
 /* Batches compressed: into_record_data (nisshi-sans-io/src/record/deflated.rs:341-386), which
  * deflated::Batch::try_from(inflated::Batch) (deflated.rs:392-409) calls with the batch's codec, for
- * its Lz4 arm (deflated.rs:362-371: the lz4 crate's Encoder, liblz4's frame format) and its Gzip arm
- * (deflated.rs:341-357: flate2's GzEncoder).  A frame of uncompressed batches goes in -- what
- * nisshi_hip_encode_dev writes -- and the same frame comes out with every batch whose d_codec[b]
- * is 3 or 1 rewritten: its record data one LZ4 frame (independent blocks of 16 KiB, no checksums,
- * no content size; a block that does not shrink is stored) or one gzip member (the header
- * flate2 writes; DEFLATE blocks of 16 KiB in the fixed code of RFC 1951 3.2.6, or stored where
- * that does not shrink them; CRC-32 and length in the trailer), its batch_length that of the
- * compressed data, the codec in its attributes, its crc that of the new bytes.
- * d_codec[b] 0: the batch is copied.  4 (zstd), which the reference compresses, and 2 (Snappy),
- * which it refuses (Error::UnexpectedType): not produced here, the batch is copied as it came
- * with NISSHI_COMPRESSED, for the caller's own path.  Above 4: copied, NISSHI_UNKNOWN_COMPRESSION.
+ * its three arms: Lz4 (deflated.rs:362-371: the lz4 crate's Encoder, liblz4's frame format), Gzip
+ * (deflated.rs:341-357: flate2's GzEncoder) and Zstd (deflated.rs:373-386: the zstd crate's
+ * Encoder).  A frame of uncompressed batches goes in -- what nisshi_hip_encode_dev writes -- and
+ * the same frame comes out with every batch whose d_codec[b] is 3, 1 or 4 rewritten: its record
+ * data one LZ4 frame (independent blocks of 16 KiB, no checksums, no content size; a block that
+ * does not shrink is stored), one gzip member (the header flate2 writes; DEFLATE blocks of 16 KiB
+ * in the fixed code of RFC 1951 3.2.6, or stored where that does not shrink them; CRC-32 and
+ * length in the trailer) or one zstd frame (no content size, no checksum, window 64 KiB; blocks
+ * of 16 KiB with raw literals and sequences in the predefined tables of RFC 8878, or raw where
+ * that does not shrink them), its batch_length that of the compressed data, the codec in its
+ * attributes, its crc that of the new bytes.
+ * d_codec[b] 0: the batch is copied.  2 (Snappy), which the reference refuses to write
+ * (Error::UnexpectedType): the batch is copied as it came with NISSHI_COMPRESSED, for the
+ * caller's own path.  Above 4: copied, NISSHI_UNKNOWN_COMPRESSION.
  * A batch to be compressed whose header does not hold (shorter than 61 bytes, a batch_length
  * that is not its length, codec bits already set): copied, NISSHI_MALFORMED.
  * Which bytes a compressor writes is its own choice (the reference holds no vector of compressed

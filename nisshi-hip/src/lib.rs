@@ -424,10 +424,10 @@ impl Codec {
     }
 
     /// `nisshi_hip_deflate`: a frame of uncompressed batches (what `encode` writes) with every batch whose
-    /// `codec` is 3 or 1 compressed as `into_record_data`'s Lz4 and Gzip arms do (deflated.rs:341-371): its
-    /// record data one LZ4 frame or one gzip member, `batch_length`, the codec bits and the crc to match.
-    /// `codec` 0: the batch as it came.  2 and 4 are not produced on the device: the batch comes back as it
-    /// went in with `Status::Compressed`, for the caller's own `into_record_data`.  Returns the frame's bytes, the start of each batch and a status a batch.
+    /// `codec` is 3, 1 or 4 compressed as `into_record_data`'s Lz4, Gzip and Zstd arms do (deflated.rs:341-386):
+    /// its record data one LZ4 frame, gzip member or zstd frame, `batch_length`, the codec bits and the crc to
+    /// match.  `codec` 0: the batch as it came.  2 (Snappy) is not produced: the batch comes back as it went in
+    /// with `Status::Compressed`, for the caller's own `into_record_data` (which refuses it too).  Returns the frame's bytes, the start of each batch and a status a batch.
     pub fn deflate(&mut self, blob: &[u8], batch_off: &[u64], codec: &[u8]) -> Result<(Vec<u8>, Vec<u64>, Vec<Status>, Totals)> {
         let n = Self::checked_batches(blob, batch_off, "nisshi_hip_deflate")?;
         if codec.len() != n {

@@ -545,7 +545,7 @@ class Codec:
         return out[:int(totals.out_bytes)].tobytes(), out_off, status[:n_b], totals
 
     def deflate_dev(self, d_blob, blob_len: int, d_batch_off, n_batches: int, d_codec):
-        """A frame of uncompressed batches with those whose codec is 3 (LZ4) or 1 (gzip) compressed.  Asks for the room first,
+        """A frame of uncompressed batches with those whose codec is 3 (LZ4), 1 (gzip) or 4 (zstd) compressed.  Asks for the room first,
         then allocates the output: returns (d_out tensor, d_out_off tensor, d_status tensor, totals)."""
         import torch
         d_out_off = torch.zeros(n_batches + 1, dtype=torch.int64, device=self.device)

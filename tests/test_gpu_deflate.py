@@ -1,11 +1,11 @@
-"""The LZ4 and gzip deflate (into_record_data's Lz4 and Gzip arms, nisshi-sans-io/src/record/deflated.rs:341-371,
+"""The LZ4, gzip and zstd deflate (into_record_data's three arms, nisshi-sans-io/src/record/deflated.rs:341-386,
 as deflated::Batch::try_from(inflated::Batch) calls it, deflated.rs:392-409) through the C ABI.  The reference
 holds no vector of compressed output and a compressor's bytes are its own choice, so parity here is the round
 trip: what the device compressed must inflate -- by the CPU checker's restatement of the frame format, and by the
 device's own inflate -- to the batch it was made from, with the header a compressed batch has (batch_length,
 codec bits, a CRC that the checker's CRC-32C confirms); and it must have got smaller where there was
 anything to find; a gzip member must also be one to Python's zlib (gzip.decompress checks header, blocks, CRC-32
-and length).  **Parity of the compressed bytes themselves is unpinned** (the reference has no fixture)."""
+and length) and a zstd frame one to libzstd (pyarrow's decompress).  **Parity of the compressed bytes themselves is unpinned** (the reference has no fixture)."""
 import gzip
 import struct
 
@@ -39,21 +39,25 @@ def check_round_trip(codec, batches, codecs):
     assert len(got) == int(got_off[-1]) == totals.out_bytes
     out = split(got, got_off)
     for b, (was, now, want, st) in enumerate(zip(batches, out, codecs, status)):
-        if want in (1, 3) and st == C.OK:
+        if want in (1, 3, 4) and st == C.OK:
             assert now[:8] == was[:8] and now[12:17] == was[12:17]                       # base offset, epoch, magic
             assert struct.unpack_from(">i", now, 8)[0] == len(now) - 12                  # batch_length
             assert struct.unpack_from(">h", now, 21)[0] == (struct.unpack_from(">h", was, 21)[0] | want)
             assert now[23:61] == was[23:61]                                              # the rest of the header
             assert struct.unpack_from(">I", now, 17)[0] == oracle.crc32c(now[21:])
-            st_i, data = (oracle.lz4_inflate if want == 3 else oracle.gzip_inflate)(now[61:])
+            st_i, data = {3: oracle.lz4_inflate, 1: oracle.gzip_inflate, 4: oracle.zstd_inflate}[want](now[61:])
             assert st_i == C.OK and data == was[61:], b
             if want == 1:
                 # a gzip member as Python's zlib reads it: header, blocks, CRC-32 and length of the trailer
                 assert gzip.decompress(now[61:]) == was[61:], b
+            if want == 4 and len(was) > 61:
+                # a zstd frame as libzstd reads it (pyarrow's)
+                import pyarrow as pa
+                assert pa.decompress(now[61:], decompressed_size=len(was) - 61, codec="zstd", asbytes=True) == was[61:], b
         else:
             assert now == was, b
     # the device's own inflate gives the frame back (but for the crc field, which stays the compressed batch's)
-    if any(c in (1, 3) for c in codecs):
+    if any(c in (1, 3, 4) for c in codecs):
         back, back_off, back_status, _ = codec.inflate(got, got_off)
         for b, (was, now) in enumerate(zip(batches, split(back, back_off))):
             assert now[:17] == was[:17] and now[21:] == was[21:], b
@@ -80,7 +84,7 @@ def records_batch(n, seed, words=True):
     return build_batch(dict(base_offset=1000 * seed, last_offset_delta=max(n - 1, 0)), records)
 
 
-@pytest.mark.parametrize("want", [3, 1])
+@pytest.mark.parametrize("want", [3, 1, 4])
 def test_batches_of_records_get_smaller_and_come_back(codec, want):
     batches = [records_batch(n, 10 + i) for i, n in enumerate((1, 5, 40, 300, 1000, 2500))]
     out, status, totals = check_round_trip(codec, batches, [want] * len(batches))
@@ -88,7 +92,7 @@ def test_batches_of_records_get_smaller_and_come_back(codec, want):
     assert sum(map(len, out[3:])) < 0.6 * sum(map(len, batches[3:]))
 
 
-@pytest.mark.parametrize("want", [3, 1])
+@pytest.mark.parametrize("want", [3, 1, 4])
 def test_sizes_around_the_blocks_and_the_ends(codec, want):
     """Record data of 0 bytes (a frame with no block), of a few bytes (all literals: no match may start in the last
     twelve), around one and two blocks of 16 KiB, of long runs (matches of thousands of bytes, lengths around 15 and
@@ -126,13 +130,13 @@ def test_codecs_that_are_not_produced_and_headers_that_do_not_hold(codec):
     batches = [good, good, good, good, good, good, bytes(compressed), short, bytes(wrong_length), good, bytes(compressed)]
     codecs = [0, 1, 2, 4, 5, 3, 3, 3, 3, 3, 1]
     out, status, totals = check_round_trip(codec, batches, codecs)
-    assert list(status) == [C.OK, C.OK, C.COMPRESSED, C.COMPRESSED, C.UNKNOWN_COMPRESSION, C.OK,
+    assert list(status) == [C.OK, C.OK, C.COMPRESSED, C.OK, C.UNKNOWN_COMPRESSION, C.OK,
                             C.MALFORMED, C.MALFORMED, C.MALFORMED, C.OK, C.MALFORMED]
-    assert totals.n_failed == 7
-    assert len(out[5]) < len(good) and out[9] == out[5] and len(out[1]) < len(good)
+    assert totals.n_failed == 6
+    assert len(out[5]) < len(good) and out[9] == out[5] and len(out[1]) < len(good) and len(out[3]) < len(good)
 
 
-@pytest.mark.parametrize("want", [3, 1])
+@pytest.mark.parametrize("want", [3, 1, 4])
 def test_encode_then_deflate_then_inflate_then_decode(codec, want):
     """The chain a fetch of a topic with a codec makes: columns -> encode -> deflate; and back: inflate -> decode
     gives the columns of the uncompressed frame."""

@@ -31,5 +31,5 @@ put("operators", {"note": "HIP-event kernel times (ms) at the C2 size: tools/sto
                           "and tools/ops_time.py (fetch, encode of its batches, compaction)",
                   "storage_time": last_json("storage_time"), "ops_time": last_json("ops_time")})
 put("inflate", {c: last_json(f"inflate_{c}") for c in ("snappy", "lz4", "gzip", "zstd")})
-put("deflate", {"lz4": last_json("deflate"), "gzip": last_json("deflate_gzip")})
+put("deflate", {"lz4": last_json("deflate"), "gzip": last_json("deflate_gzip"), "zstd": last_json("deflate_zstd")})
 print("collected", tag, source_hash())

@@ -1,4 +1,4 @@
-"""Time and ratio of the deflate (CODEC=lz4, the default, or gzip in the environment): the batch of
+"""Time and ratio of the deflate (CODEC=lz4, the default, gzip or zstd in the environment): the batch of
 tools/inflate_time.py (a thousand small records: keys, values of words, two headers) repeated COUNT times (8192 by
 default), compressed on the device; liblz4 (pyarrow's) or zlib on the same record data for the ratio.
 python tools/deflate_time.py [COUNT]"""
@@ -24,7 +24,7 @@ off = np.arange(count + 1, dtype=np.uint64) * len(plain)
 codec = hip.Codec(0)
 d_blob, d_off = codec.to_device(blob, off)
 which = os.environ.get("CODEC", "lz4")
-d_codec = torch.full((count,), {"lz4": 3, "gzip": 1}[which], dtype=torch.uint8, device=codec.device)
+d_codec = torch.full((count,), {"lz4": 3, "gzip": 1, "zstd": 4}[which], dtype=torch.uint8, device=codec.device)
 res = {"codec": which, "batches": count, "plain_bytes": len(blob)}
 for rep in range(3):
     torch.cuda.synchronize()
@@ -40,6 +40,10 @@ if which == "gzip":
     import zlib
     for level in (1, 6):
         res[f"zlib_level{level}_ratio"] = round((61 + 18 + len(zlib.compress(plain[61:], level)) - 6) / len(plain), 3)
+elif which == "zstd":
+    import pyarrow as pa
+    for level in (1, 3):
+        res[f"libzstd_level{level}_ratio"] = round((61 + len(pa.Codec("zstd", compression_level=level).compress(plain[61:], asbytes=True))) / len(plain), 3)
 else:
     try:
         import pyarrow as pa

@@ -19,4 +19,5 @@ for c in snappy lz4 gzip zstd; do
 done
 timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate.json 2> $o/${tag}_deflate.err
 CODEC=gzip timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate_gzip.json 2> $o/${tag}_deflate_gzip.err
+CODEC=zstd timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate_zstd.json 2> $o/${tag}_deflate_zstd.err
 echo "inflate and deflate done"
