@@ -106,6 +106,12 @@ def test_sizes_around_the_blocks_and_the_ends(codec, want):
     datas.append(b"".join(bytes([i % 251]) * (i % 300 + 1) for i in range(400)))
     datas.append(b"".join(bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) + b"Z" * int(k2)
                           for k, k2 in zip(rng.integers(0, 40, 300), rng.integers(4, 300, 300))))
+    # many short matches (four-byte words of a small vocabulary: a sequence every few bytes), and literal runs of
+    # hundreds of bytes between matches (lengths whose codes take extra bits)
+    words = [bytes(rng.integers(0, 256, 4, dtype=np.uint8)) for _ in range(40)]
+    datas.append(b"".join(words[int(k)] for k in rng.integers(0, 40, 9000)))
+    chunk = bytes(rng.integers(0, 256, 90, dtype=np.uint8))
+    datas.append(b"".join(bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) + chunk for k in rng.integers(60, 700, 120)))
     head = records_batch(0, 1)[:61]
     batches = []
     for d in datas:
@@ -114,7 +120,8 @@ def test_sizes_around_the_blocks_and_the_ends(codec, want):
         batches.append(bytes(h) + d)      # (the record data need not be records: the compressor does not look)
     out, status, totals = check_round_trip(codec, batches, [want] * len(batches))
     assert (status == C.OK).all()
-    assert len(out[-3]) < 600            # 70 000 zero bytes
+    assert len(out[-5]) < 600            # 70 000 zero bytes
+    assert len(out[-2]) < 0.8 * len(batches[-2]) and len(out[-1]) < len(batches[-1])
     if want == 1:
         # random bytes: stored blocks, five bytes a block and the member's eighteen
         assert len(out[8]) <= len(batches[8]) + 18 + 5 * 2
