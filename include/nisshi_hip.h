@@ -589,11 +589,11 @@ int nisshi_hip_inflate(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_l
  * (deflated.rs:341-357: flate2's GzEncoder) and Zstd (deflated.rs:373-386: the zstd crate's
  * Encoder).  A frame of uncompressed batches goes in -- what nisshi_hip_encode_dev writes -- and
  * the same frame comes out with every batch whose d_codec[b] is 3, 1 or 4 rewritten: its record
- * data one LZ4 frame (independent blocks of 16 KiB, no checksums, no content size; a block that
- * does not shrink is stored), one gzip member (the header flate2 writes; DEFLATE blocks of 16 KiB
+ * data one LZ4 frame (independent blocks of 8 KiB, no checksums, no content size; a block that
+ * does not shrink is stored), one gzip member (the header flate2 writes; DEFLATE blocks of 8 KiB
  * in the fixed code of RFC 1951 3.2.6, or stored where that does not shrink them; CRC-32 and
  * length in the trailer) or one zstd frame (no content size, no checksum, window 64 KiB; blocks
- * of 16 KiB with raw literals and sequences in the predefined tables of RFC 8878, or raw where
+ * of 8 KiB with raw literals and sequences in the predefined tables of RFC 8878, or raw where
  * that does not shrink them), its batch_length that of the compressed data, the codec in its
  * attributes, its crc that of the new bytes.
  * d_codec[b] 0: the batch is copied.  2 (Snappy), which the reference refuses to write

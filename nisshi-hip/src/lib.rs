@@ -439,7 +439,7 @@ impl Codec {
         let mut out_off = vec![0u64; n + 1];
         let mut status = vec![0i32; n.max(1)];
         let mut totals = Totals::default();
-        // (a batch grows by a few bytes a 16 KiB block at most)
+        // (a batch grows by a few bytes an 8 KiB block at most)
         let mut out = vec![0u8; blob.len() + blob.len() / 512 + 64 * n + 64];
         let st = unsafe {
             ffi::nisshi_hip_deflate(

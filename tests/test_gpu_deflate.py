@@ -95,11 +95,11 @@ def test_batches_of_records_get_smaller_and_come_back(codec, want):
 @pytest.mark.parametrize("want", [3, 1, 4])
 def test_sizes_around_the_blocks_and_the_ends(codec, want):
     """Record data of 0 bytes (a frame with no block), of a few bytes (all literals: no match may start in the last
-    twelve), around one and two blocks of 16 KiB, of long runs (matches of thousands of bytes, lengths around 15 and
+    twelve), around one, two and four blocks of 8 KiB, of long runs (matches of thousands of bytes, lengths around 15 and
     255 + 15), and of random bytes (stored blocks)."""
     rng = np.random.default_rng(3)
     datas = [b"", b"a", b"abcdefgh", bytes(12), bytes(13), bytes(19), b"ab" * 40]
-    for n in (16383, 16384, 16385, 32768, 32769, 50000):
+    for n in (8191, 8192, 8193, 16383, 16384, 16385, 32768, 32769, 50000):
         datas.append((b"0123456789abcdef" * (n // 16 + 1))[:n])
         datas.append(bytes(rng.integers(0, 256, n, dtype=np.uint8)))
     datas.append(bytes(70000))
