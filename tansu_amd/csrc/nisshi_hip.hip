@@ -15,6 +15,7 @@
 //   second_pass_kernel    what the fused kernel listed: large batches, batches whose headers did
 //                         not fit their expected slots, the sequential walk for exact error outcomes
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
@@ -2592,7 +2593,8 @@ __device__ __forceinline__ void decode_unit(bool seg, uint32_t b, uint32_t chunk
             }
             for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
             k0 = uni(sum);
-            if (!known) do_walk = none = false;  // (kSegFailed below)
+            // (a sum at or past the batch's record count can only be wrong, and would put records in another batch's slots)
+            if (!known || (do_walk && k0 >= count)) do_walk = none = false;  // (kSegFailed below)
         }
         // every record is taken to have the header count of the batch's first: the chunk's headers start k0 such records in
         uint32_t hc = count ? expect / count : 0;

@@ -4,6 +4,7 @@ starts, which record it is, how many headers a record has); a batch whose chunks
 do not join up is walked by one wave.  Either way the columns are the sequential
 walk's (deflated.rs:431-442 with record.rs:254-277): against the oracle, on batches
 built to take every way through."""
+import os
 import struct
 
 import numpy as np
@@ -203,6 +204,50 @@ def test_compacted_batches_through_the_other_entry_points(codec):
         assert_same(got, want, n_b)
     finally:
         fresh.close()
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_compacted_batches_of_many_makes(codec, seed):
+    """Drawn at random: how many records, which of them a compaction took (runs of survivors and of gaps of
+    drawn lengths), value and key sizes (one size a batch, or a few sizes in stretches), header counts (none, or
+    the same for every record), timestamps that jump, a last_offset_delta beyond the last record.  Whatever
+    the chunks make of a batch -- joined, or walked whole -- the columns are the checker's."""
+    rng = np.random.default_rng(seed)
+    batches, base = [], 0
+    for b in range(14):
+        n = int(rng.integers(1500, 9000))
+        # survivors: runs of kept records between gaps
+        kept, at = [], 0
+        while len(kept) < n:
+            run = int(rng.integers(1, 400))
+            kept.extend(range(at, at + run))
+            at += run + int(rng.integers(0, 3 if b % 3 else 300))
+        kept = kept[:n]
+        sizes = [int(rng.integers(20, 300)) for _ in range(1 if b % 2 else 3)]
+        stretch = int(rng.integers(200, 3000))
+        hc = int(rng.integers(0, 3)) if b % 4 else 0
+        klen = int(rng.integers(0, 30))
+        jump = int(rng.integers(1, 5000))
+        recs = records(n, rng, od=lambda i: kept[i], ts=lambda i: jump * kept[i] - (i % 7),
+                       value=lambda i: sizes[(i // stretch) % len(sizes)], headers=lambda i: hc,
+                       key=lambda i: (b"k" * klen) if klen else None)
+        batches.append(build_batch(dict(base_offset=base, last_offset_delta=kept[-1] + int(rng.integers(0, 50))), recs))
+        base += kept[-1] + 100
+    frame = patched(codec, batches)
+    for beside in ("1", "0"):
+        os.environ["NISSHI_CHUNKS_BESIDE"] = beside
+        os.environ["NISSHI_ADAPTIVE"] = "0"
+        try:
+            fresh = hip.Codec(0)
+        finally:
+            del os.environ["NISSHI_CHUNKS_BESIDE"], os.environ["NISSHI_ADAPTIVE"]
+        try:
+            whole = walked_whole(fresh, frame)
+            assert whole <= len(batches)
+            if beside == "1":
+                assert whole <= 3       # (batches of one size join up; a change of size inside a chunk is found as well)
+        finally:
+            fresh.close()
 
 
 def test_compacted_batches_that_the_count_cannot_follow(codec):
