@@ -228,8 +228,11 @@ def test_compacted_batches_of_many_makes(codec, seed):
         hc = int(rng.integers(0, 3)) if b % 4 else 0
         klen = int(rng.integers(0, 30))
         jump = int(rng.integers(1, 5000))
+        # (now and then what no guess holds for: a header count, or sizes, that change from record to record)
+        odd_hc, odd_size = b % 7 == 5, b % 7 == 6
         recs = records(n, rng, od=lambda i: kept[i], ts=lambda i: jump * kept[i] - (i % 7),
-                       value=lambda i: sizes[(i // stretch) % len(sizes)], headers=lambda i: hc,
+                       value=lambda i: sizes[(i // stretch) % len(sizes)] + (i % 5 if odd_size else 0),
+                       headers=lambda i: hc + (i % 3 == 0 if odd_hc else 0),
                        key=lambda i: (b"k" * klen) if klen else None)
         batches.append(build_batch(dict(base_offset=base, last_offset_delta=kept[-1] + int(rng.integers(0, 50))), recs))
         base += kept[-1] + 100
@@ -245,7 +248,7 @@ def test_compacted_batches_of_many_makes(codec, seed):
             whole = walked_whole(fresh, frame)
             assert whole <= len(batches)
             if beside == "1":
-                assert whole <= 3       # (batches of one size join up; a change of size inside a chunk is found as well)
+                assert whole <= 5       # (batches of one size join up; a change of size inside a chunk is found as well)
         finally:
             fresh.close()
 

@@ -127,6 +127,41 @@ def test_sizes_around_the_blocks_and_the_ends(codec, want):
         assert len(out[8]) <= len(batches[8]) + 18 + 5 * 2
 
 
+@pytest.mark.parametrize("seed", [41, 42])
+def test_record_data_drawn_at_random(codec, seed):
+    """Record data pieced together at random -- runs of one byte, random bytes, text of a small vocabulary,
+    repeats of what came a drawn distance earlier -- of drawn lengths up to a few blocks, through the three
+    codecs in one call."""
+    rng = np.random.default_rng(seed)
+    vocab = [b"offset", b"partition", b"topic", b"key", b"value", b"timestamp", b"\x00\x00\x00", b"{\"id\":", b"},", b"null"]
+    head = records_batch(0, 1)[:61]
+    batches, codecs = [], []
+    for i in range(45):
+        want = int(rng.integers(0, 30000)) if i % 5 else int(rng.integers(0, 40))
+        d = bytearray()
+        while len(d) < want:
+            kind = int(rng.integers(0, 4))
+            k = int(rng.integers(1, 600))
+            if kind == 0:
+                d += bytes([int(rng.integers(0, 256))]) * k
+            elif kind == 1:
+                d += bytes(rng.integers(0, 256, k, dtype=np.uint8))
+            elif kind == 2:
+                d += b" ".join(vocab[int(x)] for x in rng.integers(0, len(vocab), k // 6 + 1))
+            elif d:
+                back = int(rng.integers(1, min(len(d), 20000) + 1))
+                for _ in range(k):
+                    d.append(d[-back])
+        d = bytes(d[:want])
+        h = bytearray(head)
+        struct.pack_into(">i", h, 8, 49 + len(d))
+        batches.append(bytes(h) + d)
+        codecs.append((3, 1, 4)[i % 3])
+    out, status, totals = check_round_trip(codec, batches, codecs)
+    assert (status == C.OK).all()
+    assert sum(map(len, out)) < 0.8 * sum(map(len, batches))
+
+
 def test_codecs_that_are_not_produced_and_headers_that_do_not_hold(codec):
     good = records_batch(200, 5)
     compressed = bytearray(good)
