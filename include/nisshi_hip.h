@@ -591,8 +591,8 @@ int nisshi_hip_inflate(nisshi_hip_ctx *ctx, const uint8_t *blob, uint64_t blob_l
  * the same frame comes out with every batch whose d_codec[b] is 3, 1 or 4 rewritten: its record
  * data one LZ4 frame (independent blocks of 8 KiB, no checksums, no content size; a block that
  * does not shrink is stored), one gzip member (the header flate2 writes; DEFLATE blocks of 8 KiB
- * in the fixed code of RFC 1951 3.2.6, or stored where that does not shrink them; CRC-32 and
- * length in the trailer) or one zstd frame (no content size, no checksum, window 64 KiB; blocks
+ * each in a code of its own, in the fixed code of RFC 1951 3.2.6, or stored, whichever is
+ * smallest; CRC-32 and length in the trailer) or one zstd frame (no content size, no checksum, window 64 KiB; blocks
  * of 8 KiB with raw literals and sequences in the predefined tables of RFC 8878, or raw where
  * that does not shrink them), its batch_length that of the compressed data, the codec in its
  * attributes, its crc that of the new bytes.
