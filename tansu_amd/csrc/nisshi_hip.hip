@@ -2215,9 +2215,10 @@ __device__ __forceinline__ bool find_record_start(const View &ring, uint32_t bia
 // Places not looked at are taken to hold records: the count is a guess, as the
 // chunk's start is, and segments_join checks both -- a chunk's walk ends at the
 // record index that the next one started with only if every count before was right.
-// A chunk whose sizes change more often than kIndexTries times is not counted
-// (the batch is then one wave's).  The wave leaves its count for the waves of the
-// chunks behind it and adds up those of the chunks before it (decode_unit).
+// A chunk whose sizes change more often than kIndexTries times, or twice in a row
+// after a record or two, has its records counted one by one (hops_from).  The wave
+// leaves its count for the waves of the chunks behind it and adds up those of the
+// chunks before it (decode_unit).
 constexpr int kIndexTries = 16;
 constexpr uint32_t kCountFailed = 0xffffu;  // a chunk's count as it is left for the chunks behind it: sixteen bits under the call's tag
 constexpr uint64_t kIndexWait = 50000;      // how long a chunk's wave waits for the counts before it: 500 us of the 100 MHz clock
@@ -2246,11 +2247,87 @@ struct MemoryView {
     }
 };
 
+// The records that start in [pos, pos_end), the first at pos, counted one by one:
+// from a record's length to the next record (its length in two bytes at most, no
+// bit of its attributes in use: what plausible_record asks of a record's first
+// bytes), for the records whose sizes change too often for records_from's strides.
+// The chunk passes through the lanes' registers kHopRows KiB at a time, sixteen bytes
+// of a KiB a lane: a hop reads its bytes from the lanes that hold them, and memory is
+// waited for once a set of rows (a set's last row is the next set's first: a hop's
+// bytes may lie across two rows).  (The next set on its way while the count goes
+// through this one was tried: with loads under way around the loop the compiler has
+// every hop wait for all of them.)  Up to kHopsMax records a
+// chunk (kSegFailed beyond: thirty-two bytes a record on average fill a chunk with
+// that many).
+constexpr uint32_t kHopsMax = 2048;
+constexpr int kHopRows = 8;
+struct HopRows {
+    u32x4 q[kHopRows + 1];
+    __device__ __forceinline__ void load(const uint8_t *grid, uint32_t limit, uint32_t r, int lane) {
+#pragma unroll
+        for (int j = 0; j <= kHopRows; j++) {
+            uint32_t at = (r + (uint32_t)j) * kRowBytes + (uint32_t)lane * 16;
+            q[j] = at + 16 <= limit ? *reinterpret_cast<const u32x4 *>(grid + at) : u32x4{0, 0, 0, 0};
+        }
+    }
+};
+
+// The hops that start in rows r .. r + kHopRows - 1, which `rows` holds.  False: the count is over (*result).
+// A hop is a few vector instructions and two dozen scalar ones: with the first word of the lane behind it a
+// lane holds the four bytes at any of its sixteen positions, and the one lane that holds the hop's position
+// hands them over.  Whether the bytes were a record's is looked at a row at a time (a hop goes forward
+// whatever it read, by a length of two bytes at most: the row's loop ends).
+__device__ __forceinline__ bool hops_in(const HopRows &rows, uint32_t &r, uint32_t bias, uint32_t &pos, uint32_t pos_end,
+                                        uint32_t data_len, uint32_t &counted, uint32_t counted_max, uint32_t *result, int lane) {
+#pragma unroll
+    for (int s = 0; s < kHopRows; s++) {
+        uint32_t behind = __shfl_down(rows.q[s].x, 1, 64);
+        uint32_t next_row = (uint32_t)__builtin_amdgcn_readlane((int)rows.q[s + 1].x, 0);
+        u32x4 low = rows.q[s], high = {low.y, low.z, low.w, lane == kWave - 1 ? next_row : behind};
+        uint32_t row_end = (r + 1) * kRowBytes - bias;  // (the record data's position of the next row's first byte)
+        uint32_t stop = row_end < pos_end ? row_end : pos_end;
+        uint32_t bad = 0;
+        while (pos < stop) {
+            uint32_t at = pos + bias;
+            uint32_t part = (at >> 2) & 3u;
+            uint32_t mine = __builtin_amdgcn_alignbyte(high[part], low[part], at & 3u);
+            uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)((at >> 4) & 63u));
+            uint32_t two = (head >> 7) & 1u;                        // the length goes on in a second byte
+            uint32_t v = (head & 0x7fu) | (two ? (head >> 1) & 0x3f80u : 0u);
+            uint32_t size = 1 + two + (v >> 1);
+            uint32_t attributes = (head >> (two ? 16 : 8)) & 0xffu;
+            bad |= (two & (head >> 15)) | (v & 1u) | (v < 12 ? 1u : 0u) | attributes | (size > data_len - pos ? 1u : 0u);
+            pos += size;
+            counted += 1;
+        }
+        *result = kSegFailed;
+        if (bad || counted > counted_max) return false;
+        if (pos >= pos_end) {
+            *result = counted;
+            return false;
+        }
+        r += 1;
+    }
+    return true;
+}
+
+__device__ __forceinline__ uint32_t hops_from(const uint8_t *grid, uint32_t limit, uint32_t bias, uint32_t pos, uint32_t pos_end,
+                                              uint32_t data_len, uint32_t counted, int lane) {
+    // (every lane has the same of each of these: in scalar registers, and the loop's branches scalar ones)
+    bias = uni(bias), pos = uni(pos), pos_end = uni(pos_end), data_len = uni(data_len), counted = uni(counted);
+    uint32_t r = (pos + bias) / kRowBytes, result = kSegFailed, counted_max = counted + kHopsMax;
+    for (;;) {
+        HopRows held;
+        held.load(grid, limit, r, lane);
+        if (!hops_in(held, r, bias, pos, pos_end, data_len, counted, counted_max, &result, lane)) return result;
+    }
+}
+
 // The records that start in [pos, pos_end) of the record data, the first of them at
 // pos (kSegFailed: not counted).
 __device__ __forceinline__ uint32_t records_from(const MemoryView &view, uint32_t bias, uint32_t pos, uint32_t pos_end,
                                                  uint32_t data_len, int lane) {
-    uint32_t counted = 0;
+    uint32_t counted = 0, poor = 0;
     for (int tries = 0; tries < kIndexTries; tries++) {
         if (pos >= pos_end) return counted;
         uint32_t size;
@@ -2278,8 +2355,11 @@ __device__ __forceinline__ uint32_t records_from(const MemoryView &view, uint32_
         counted += good_to + 1;
         pos += (good_to + 1) * size;
         if (good_to + 1 == m) return counted;
+        // (two sizes that held for a record or two: these records are not of a size for a stretch)
+        poor += good_to < 2 ? 1 : 0;
+        if (poor == 2) break;
     }
-    return kSegFailed;
+    return hops_from(view.grid, view.limit, bias, pos, pos_end, data_len, counted, lane);
 }
 
 // Whether the chunks of batch b, whose work items start at `first`, join up.

@@ -200,12 +200,13 @@ def _uniform_ints(seed: int, n: int, lo: int, hi: int) -> np.ndarray:
 
 
 def make_var_batches(n_batches: int, records: int, seed: int, key_len: int = 16, val_range=(32, 96),
-                     n_headers: int = 2, hkey_len: int = 8, hval_range=(0, 32)):
+                     n_headers: int = 2, hkey_len: int = 8, hval_range=(0, 32), delta=None):
     """Batches whose records differ in size from one to the next: every record
     draws its value length from val_range and the value length of each of its
     headers from hval_range (both inclusive), everything else as in make_batches
-    (offset_delta = timestamp_delta = index in the batch, random payload bytes).
-    Returns (blob, batch_off, n_records, n_headers); CRC fields are zero.
+    (offset_delta = timestamp_delta = index in the batch, or `delta` of it -- a function
+    of the array of indices -- for batches that do not number their records; random
+    payload bytes).  Returns (blob, batch_off, n_records, n_headers); CRC fields are zero.
 
     The blob is filled with random bytes first and the structural bytes (lengths,
     counts, deltas, attributes) are written over them, so the whole input is built
@@ -218,6 +219,11 @@ def make_var_batches(n_batches: int, records: int, seed: int, key_len: int = 16,
         return np.where(z < 128, 1, 2).astype(np.int64)
 
     idx = np.tile(np.arange(records, dtype=np.int64), n_batches)
+    last_delta = None
+    if delta is not None:
+        idx = np.asarray(delta(idx), dtype=np.int64)
+        last_delta = int(idx[records - 1])
+        assert last_delta < (1 << 13)
     vl = _uniform_ints(seed + 1, n, *val_range)
     hvl = _uniform_ints(seed + 2, n * max(n_headers, 1), *hval_range).reshape(n, max(n_headers, 1))[:, :n_headers]
     kl = np.full(n, key_len, dtype=np.int64)
@@ -253,7 +259,8 @@ def make_var_batches(n_batches: int, records: int, seed: int, key_len: int = 16,
     assert (pos == starts + rec).all()
     for b in range(n_batches):
         s = int(off[b])
-        blob[s:s + 61] = np.frombuffer(batch_header(b * records, int(data_len[b]), records), dtype=np.uint8)
+        blob[s:s + 61] = np.frombuffer(batch_header(b * records, int(data_len[b]), records, last_delta=last_delta),
+                                       dtype=np.uint8)
     return blob, off, n, n * n_headers
 
 

@@ -253,25 +253,61 @@ def test_compacted_batches_of_many_makes(codec, seed):
             fresh.close()
 
 
+def test_compacted_batches_of_records_of_every_size(codec):
+    """Sizes that change from record to record (values and keys of drawn lengths, records on both sides of
+    the 64 bytes where the length takes a second byte) in batches that do not number their records: the
+    strides of the count find nothing to hold on to and the chunk's records are counted one by one, from
+    length to length.  The chunks join up all the same, whichever launch works on them."""
+    import os
+    rng = np.random.default_rng(25)
+    gaps = lambda i: 2 * i + 1
+    v_len, k_len = rng.integers(0, 200, 12000), rng.integers(0, 40, 12000)
+    values = build_batch(dict(base_offset=0, last_offset_delta=gaps(11999)),
+                         records(12000, rng, od=gaps, value=lambda i: 20 + int(v_len[i])))
+    keys = build_batch(dict(base_offset=30000, last_offset_delta=synth.every_third_missing(7999) + 9),
+                       records(8000, rng, od=synth.every_third_missing, ts=lambda i: 5 * i, headers=lambda i: 1,
+                               value=lambda i: int(v_len[i]) // 2, key=lambda i: b"k" * int(k_len[i]) if k_len[i] else None))
+    # (one size for a stretch, then every size: the strides hand over to the hops inside a chunk)
+    mixed = build_batch(dict(base_offset=60000, last_offset_delta=gaps(5999)),
+                        records(6000, rng, od=gaps, value=lambda i: 100 if i % 1500 < 900 else 60 + int(v_len[i]) % 90))
+    small = [build_batch(dict(base_offset=90000 + 10 * i, last_offset_delta=9), records(10, rng)) for i in range(4)]
+    assert all(len(b) > 6 * CHUNK for b in (values, keys, mixed))
+    frame = patched(codec, small[:2] + [values, keys] + small[2:] + [mixed])
+    for beside in ("1", "0"):
+        os.environ["NISSHI_CHUNKS_BESIDE"] = beside
+        os.environ["NISSHI_ADAPTIVE"] = "0"
+        try:
+            fresh = hip.Codec(0)
+        finally:
+            del os.environ["NISSHI_CHUNKS_BESIDE"], os.environ["NISSHI_ADAPTIVE"]
+        try:
+            assert walked_whole(fresh, frame) == 0
+            assert walked_whole(fresh, frame) == 0
+        finally:
+            fresh.close()
+
+
 def test_compacted_batches_that_the_count_cannot_follow(codec):
-    """The count looks at a few places a chunk and takes records of one size to lie between them.  Where
-    that is not so -- sizes that change from record to record, one record of another size and then the old
-    size again, bytes behind the records -- the chunks do not join up (or are not counted at all) and the
-    batch is walked whole: same columns, and the context says how many such batches there were."""
+    """The count looks at a few places a chunk and takes records of one size to lie between them, or goes
+    from record to record up to a few thousand a chunk.  Where neither holds -- one record of another size
+    and then the old size again may slip through the strides, bytes behind the records, records of a dozen
+    bytes and changing sizes -- the chunks do not join up (or are not counted at all) and the batch is
+    walked whole: same columns, and the context says how many such batches there were."""
     rng = np.random.default_rng(22)
     gaps = lambda i: 2 * i + 1
-    changing = build_batch(dict(base_offset=0, last_offset_delta=gaps(3999)),
-                           records(4000, rng, od=gaps, value=lambda i: 90 + int(rng.integers(0, 30))))
     one_off = build_batch(dict(base_offset=10000, last_offset_delta=gaps(3999)),
                           records(4000, rng, od=gaps, value=lambda i: 101 if i in (700, 2500) else 100))
     tail = bytearray(build_batch(dict(base_offset=20000, last_offset_delta=gaps(1999)), records(2000, rng, od=gaps)))
     tail += bytes(rng.integers(0, 256, 3 * CHUNK, dtype=np.uint8))
     tail[8:12] = struct.pack(">i", len(tail) - 12)
-    fine = build_batch(dict(base_offset=30000, last_offset_delta=gaps(3999)), records(4000, rng, od=gaps))
-    frame, fines = patched(codec, [changing, one_off, bytes(tail), fine]), patched(codec, [fine, fine])
+    tiny = build_batch(dict(base_offset=25000, last_offset_delta=gaps(29999)),
+                       records(30000, rng, od=gaps, value=lambda i: i % 3, key=lambda i: None))
+    fine = build_batch(dict(base_offset=90000, last_offset_delta=gaps(3999)), records(4000, rng, od=gaps))
+    assert len(tiny) > 4 * CHUNK
+    frame, fines = patched(codec, [one_off, bytes(tail), tiny, fine]), patched(codec, [fine, fine])
     fresh = hip.Codec(0)
     try:
-        assert 1 <= walked_whole(fresh, frame) <= 3
+        assert 2 <= walked_whole(fresh, frame) <= 3
         assert walked_whole(fresh, fines) == 0
     finally:
         fresh.close()

@@ -107,6 +107,7 @@ def build_batch(header: dict, records) -> bytes:
     hdr = dict(magic=2, partition_leader_epoch=-1, producer_id=-1)
     hdr.update(header)
     cols, payload, src_off = C.columns_from_records([(hdr, recs)])
-    st, out, _ = oracle.encode_columns(cols, 1, payload, src_off)
+    # (room by the records' sizes: records of a few bytes outweigh their payload many times)
+    st, out, _ = oracle.encode_columns(cols, 1, payload, src_off, out_cap=sum(r.length + 5 for r in recs) + 1024)
     assert st == C.OK
     return out
