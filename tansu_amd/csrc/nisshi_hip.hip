@@ -2289,14 +2289,17 @@ __device__ __forceinline__ bool hops_in(const HopRows &rows, uint32_t &r, uint32
         uint32_t bad = 0;
         while (pos < stop) {
             uint32_t at = pos + bias;
-            uint32_t part = (at >> 2) & 3u;
-            uint32_t mine = __builtin_amdgcn_alignbyte(high[part], low[part], at & 3u);
+            // (the lane's eight bytes from the position's word on: by eight bytes, then by four)
+            bool by8 = (at & 8u) != 0, by4 = (at & 4u) != 0;
+            uint32_t a0 = by8 ? low.z : low.x, a1 = by8 ? low.w : low.y, a2 = by8 ? high.w : low.z;
+            uint32_t mine = __builtin_amdgcn_alignbyte(by4 ? a2 : a1, by4 ? a1 : a0, at & 3u);
             uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)((at >> 4) & 63u));
             uint32_t two = (head >> 7) & 1u;                        // the length goes on in a second byte
             uint32_t v = (head & 0x7fu) | (two ? (head >> 1) & 0x3f80u : 0u);
             uint32_t size = 1 + two + (v >> 1);
             uint32_t attributes = (head >> (two ? 16 : 8)) & 0xffu;
-            bad |= (two & (head >> 15)) | (v & 1u) | (v < 12 ? 1u : 0u) | attributes | (size > data_len - pos ? 1u : 0u);
+            // (v < 12, size > data_len - pos: as sign bits, every value here is far below 2^31)
+            bad |= (two & (head >> 15)) | (v & 1u) | ((v - 12u) >> 31) | attributes | ((data_len - pos - size) >> 31);
             pos += size;
             counted += 1;
         }

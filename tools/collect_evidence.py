@@ -1,5 +1,6 @@
 """Gather what tools/evidence.sh left under gpurun_out/ into tracked files of profiles/:
-<tag>_default_bench.json, <tag>_launcher_pool.json, <tag>_operators.json, <tag>_inflate.json.
+<tag>_default_bench.json, <tag>_launcher_pool.json, <tag>_operators.json, <tag>_inflate.json, <tag>_deflate.json,
+<tag>_gapped_sizes.json.
 usage: python tools/collect_evidence.py <round tag>"""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -32,4 +33,8 @@ put("operators", {"note": "HIP-event kernel times (ms) at the C2 size: tools/sto
                   "storage_time": last_json("storage_time"), "ops_time": last_json("ops_time")})
 put("inflate", {c: last_json(f"inflate_{c}") for c in ("snappy", "lz4", "gzip", "zstd")})
 put("deflate", {"lz4": last_json("deflate"), "gzip": last_json("deflate_gzip"), "zstd": last_json("deflate_zstd")})
+put("gapped_sizes", {"note": "tools/gapped_sizes_time.py: batches of 5000 records, every third gone, sizes drawn a record; "
+                             "`numbered`: the same batches with their records numbered 0, 1, 2 ...",
+                     "batches_32": last_json("gapped_sizes_32"), "batches_32_numbered": last_json("gapped_sizes_32_numbered"),
+                     "batches_512": last_json("gapped_sizes_512"), "batches_512_numbered": last_json("gapped_sizes_512_numbered")})
 print("collected", tag, source_hash())

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repository root): bash tools/evidence.sh <round tag>
 # The bench lines that go with a round's profiles: the default run, two ranks on this one GPU, the pool over one
-# and over two contexts, the operators' kernel times, the inflate of every codec.  Results under gpurun_out/<tag>_*.
+# and over two contexts, the operators' kernel times, the inflate of every codec, the compressors, large compacted batches whose records change size.  Results under gpurun_out/<tag>_*.
 set -e
 tag=${1:-r03}
 o=gpurun_out
@@ -21,3 +21,8 @@ timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate.json 2> $o/$
 CODEC=gzip timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate_gzip.json 2> $o/${tag}_deflate_gzip.err
 CODEC=zstd timeout -k 10 300 python3 tools/deflate_time.py > $o/${tag}_deflate_zstd.json 2> $o/${tag}_deflate_zstd.err
 echo "inflate and deflate done"
+timeout -k 10 200 python3 tools/gapped_sizes_time.py --batches 32 > $o/${tag}_gapped_sizes_32.json 2> $o/${tag}_gapped_sizes.err
+timeout -k 10 200 python3 tools/gapped_sizes_time.py --batches 32 --numbered > $o/${tag}_gapped_sizes_32_numbered.json 2>> $o/${tag}_gapped_sizes.err
+timeout -k 10 200 python3 tools/gapped_sizes_time.py > $o/${tag}_gapped_sizes_512.json 2>> $o/${tag}_gapped_sizes.err
+timeout -k 10 200 python3 tools/gapped_sizes_time.py --numbered > $o/${tag}_gapped_sizes_512_numbered.json 2>> $o/${tag}_gapped_sizes.err
+echo "compacted batches of changing sizes done"
