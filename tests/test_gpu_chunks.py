@@ -358,6 +358,47 @@ def test_chunks_with_records_that_do_not_decode(codec):
     assert totals.n_failed == 2 and totals.n_exact >= 3
 
 
+def test_compacted_batches_of_every_size_with_records_that_do_not_decode(codec):
+    """The same damage in batches that do not number their records and whose sizes change from record
+    to record, where a chunk's wave goes from length to length to count its records: a length that is
+    off by one in chunk 2, a length whose second byte goes on, an attributes byte with a bit set, the
+    data cut short, a count beyond the records, random bytes for a whole chunk.  Whatever the count
+    makes of them, the batch's outcome is the sequential walk's."""
+    rng = np.random.default_rng(35)
+    gaps = lambda i: 2 * i + 1
+    v_len = rng.integers(0, 200, 6000)
+    good = build_batch(dict(base_offset=0, last_offset_delta=gaps(5999)),
+                       records(6000, rng, od=gaps, value=lambda i: 20 + int(v_len[i])))
+    assert len(good) > 8 * CHUNK
+    st, cc, _, _ = oracle.decode_columns(good, offsets_of([good]))
+    # the first byte of the length of a record of a hundred bytes and more behind record 2500, from where its key
+    # starts: length (2), attributes, two deltas of two bytes, the key's length
+    which = 2500 + int(np.argmax(v_len[2500:] >= 80))
+    start = 61 + int(cc["key_off"][which]) - 1 - 2 - 2 - 1 - 2
+    assert good[start] & 0x80 and good[start + 2] == 0 and start > 21 + 2 * CHUNK
+
+    def damaged(at, how):
+        b = bytearray(good)
+        b[at] = how(b[at])
+        return bytes(b)
+
+    off_by_one = damaged(start, lambda v: v ^ 0x02)
+    goes_on = damaged(start + 1, lambda v: v | 0x80)
+    attributes = damaged(start + 2, lambda v: 0x08)
+    cut = bytearray(good)
+    cut[8:12] = struct.pack(">i", len(cut) - 12 - 40)
+    del cut[-40:]
+    over = bytearray(good)
+    over[57:61] = struct.pack(">I", 6001)
+    noise = bytearray(good)
+    noise[61 + 3 * CHUNK:61 + 4 * CHUNK] = bytes(rng.integers(0, 256, CHUNK, dtype=np.uint8))
+    batches = [good, off_by_one, goes_on, attributes, bytes(cut), bytes(over), bytes(noise), good]
+    g, c, totals, *_ = decode(codec, batches)
+    ok = [int(s) == C.OK for s in c["status"][:8]]
+    assert ok[0] and ok[7] and not ok[4] and not ok[5] and not ok[6]
+    assert totals.n_failed == 8 - sum(ok)
+
+
 def test_few_and_many_batches_give_the_same_columns(codec):
     """A call of few batches takes its batches of 128 KiB and more chunk by chunk, a
     call of many only those of 512 KiB and more: the same batch decodes to the same
