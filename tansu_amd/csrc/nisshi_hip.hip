@@ -2326,6 +2326,98 @@ __device__ __forceinline__ uint32_t hops_from(const uint8_t *grid, uint32_t limi
     }
 }
 
+// The same count by 64 chains of hops side by side, as chains_abreast finds the starts of a round:
+// the stretch is cut into 64 shares, lane 0's chain starts at pos and every other lane's at a
+// candidate, the first place in the first 192 bytes of its share that looks like the head of a
+// record (a length of two bytes that is not negative, an attributes byte of zero).  All chains hop in
+// step, each through a view of the batch in memory of its own, until a chain lands exactly on the
+// start of a chain ahead of it (one it passes without landing on was no record's start: it aims at
+// the next).  The count is the sum over the chains on the path from lane 0's, which ends with the
+// chain that passes pos_end: nothing of a chain is used unless hops from pos led to where it
+// started.  kSegFailed (and the count is hops_from's): shares of less than 200 bytes, a chain on the
+// path that is still under way after kChainSteps hops (records of less than 64 bytes have lengths of
+// one byte and are no candidates), a hop that does not read as a record.
+constexpr uint32_t kChainSteps = 48, kChainScan = 16, kChainWindows = 3;  // hops a chain; dwords a window, windows a lane looks through for its candidate
+__device__ __forceinline__ uint32_t chains_from(const uint8_t *grid, uint32_t limit, uint32_t bias, uint32_t pos,
+                                                uint32_t pos_end, uint32_t data_len, int lane) {
+    typedef uint32_t __attribute__((aligned(4))) u32_al4;
+    uint32_t stride = (pos_end - pos) / kWave;
+    if (stride < 4 * kChainScan * kChainWindows + 8) return kSegFailed;
+    // ---- the candidates
+    uint32_t start = lane == 0 ? pos : 0xffffffffu;
+#pragma unroll 1
+    for (uint32_t window = 0; window < kChainWindows; window++) {  // (64 bytes at a time: a record of 200 bytes starts in one of them)
+        if (!__any(start == 0xffffffffu)) break;
+        uint32_t q0 = ((pos + (uint32_t)lane * stride + bias) & ~3u) + window * 4 * kChainScan;  // from the batch's grid, a whole word
+        bool inside = q0 + 4 * kChainScan + 4 <= limit;
+        const u32_al4 *rp = reinterpret_cast<const u32_al4 *>(grid + (inside ? q0 : 0u));
+        uint32_t d[kChainScan + 1];
+#pragma unroll
+        for (uint32_t j = 0; j <= kChainScan; j++) d[j] = rp[j];
+        uint32_t first = 0xffffu;
+#pragma unroll
+        for (int j = (int)kChainScan - 1; j >= 0; j--) {
+            uint32_t w = d[j], nx = d[j + 1];
+            uint32_t b1 = __builtin_amdgcn_alignbit(nx, w, 8), b2 = __builtin_amdgcn_alignbit(nx, w, 16);
+            uint32_t nz = ((b2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | b2;  // bit 7 of a byte: the byte two on is not zero
+            // the byte continues, is even (no negative length), the next ends the varint, the one after is zero
+            uint32_t cand = w & ~(w << 7) & ~b1 & ~nz & 0x80808080u;
+            uint32_t at = (uint32_t)j * 4 + ((uint32_t)__builtin_ctz(cand | 0x80000000u) >> 3);
+            first = cand ? at : first;
+        }
+        uint32_t found = q0 + first - bias;
+        if (start == 0xffffffffu && inside && first != 0xffffu && q0 + first >= bias && found > pos && found + 7 <= pos_end)
+            start = found;
+    }
+    uint64_t exist = __ballot(start != 0xffffffffu);
+    auto chain_after = [&](uint32_t t) -> uint32_t {  // the next chain there is after chain t; kWave: none
+        uint64_t ahead = t >= kWave - 1 ? 0ull : exist & ~((2ull << t) - 1ull);
+        return ahead ? (uint32_t)__builtin_ctzll(ahead) : kWave;
+    };
+    // ---- the hops
+    MemoryView view(grid, limit);
+    bool alive = start != 0xffffffffu, landed = false, through = false;  // through: past pos_end, with no chain ahead
+    uint32_t pc = alive ? start : pos, cnt = 0;
+    uint32_t tgt = chain_after((uint32_t)lane);
+    uint32_t tpos = (uint32_t)__shfl((int)start, (int)(tgt < kWave ? tgt : 0u), 64);
+    tpos = tgt < kWave ? tpos : 0xffffffffu;
+#pragma unroll 1
+    for (uint32_t step = 0; step < kChainSteps; step++) {
+        bool act = alive && !landed && !through;
+        if (!__any(act)) break;
+        uint64_t w0 = view.read64((act ? pc : pos) + bias);
+        uint32_t used;
+        int32_t len;
+        bool ok = fast_varint(w0, used, len) && used <= 2 && len >= 6 && ((w0 >> (8 * used)) & 0xffu) == 0;
+        uint32_t size = used + (uint32_t)len;
+        bool take = act && ok && size <= data_len - pc;
+        if (act && !take) alive = false;  // no record here: the chain was on no record's start, or the data is damaged
+        cnt += take ? 1u : 0u;
+        pc += take ? size : 0u;
+#pragma unroll 1
+        for (uint32_t t = 0; t < kWave && __any(take && pc > tpos); t++) {  // passed a start without landing on it
+            bool passed = take && pc > tpos;
+            uint32_t nt = chain_after(passed ? tgt : 0u);
+            uint32_t np = (uint32_t)__shfl((int)start, (int)(nt < kWave ? nt : 0u), 64);
+            tgt = passed ? nt : tgt;
+            tpos = passed ? (nt < kWave ? np : 0xffffffffu) : tpos;
+        }
+        landed = landed || (take && pc == tpos);
+        through = through || (take && !landed && pc >= pos_end);
+    }
+    // ---- the chains that were landed on, in order from lane 0's
+    uint32_t ended = cnt | (tgt << 16) | (landed ? 0x800000u : 0u) | (through ? 0x1000000u : 0u);
+    uint32_t total = 0, t = 0;
+    for (uint32_t j = 0; j < kWave; j++) {
+        uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ended, (int)t);
+        total += e & 0xffffu;
+        if (e & 0x1000000u) return total;
+        if (!(e & 0x800000u)) return kSegFailed;
+        t = (e >> 16) & 0x7fu;
+    }
+    return kSegFailed;
+}
+
 // The records that start in [pos, pos_end) of the record data, the first of them at
 // pos (kSegFailed: not counted).
 __device__ __forceinline__ uint32_t records_from(const MemoryView &view, uint32_t bias, uint32_t pos, uint32_t pos_end,
@@ -2362,6 +2454,9 @@ __device__ __forceinline__ uint32_t records_from(const MemoryView &view, uint32_
         poor += good_to < 2 ? 1 : 0;
         if (poor == 2) break;
     }
+    // (records of every size: by chains of hops side by side, or failing that one by one)
+    uint32_t rest = chains_from(view.grid, view.limit, uni(bias), uni(pos), uni(pos_end), uni(data_len), lane);
+    if (rest != kSegFailed) return counted + rest;
     return hops_from(view.grid, view.limit, bias, pos, pos_end, data_len, counted, lane);
 }
 

@@ -256,8 +256,9 @@ def test_compacted_batches_of_many_makes(codec, seed):
 def test_compacted_batches_of_records_of_every_size(codec):
     """Sizes that change from record to record (values and keys of drawn lengths, records on both sides of
     the 64 bytes where the length takes a second byte) in batches that do not number their records: the
-    strides of the count find nothing to hold on to and the chunk's records are counted one by one, from
-    length to length.  The chunks join up all the same, whichever launch works on them."""
+    strides of the count find nothing to hold on to and the chunk's records are counted from length to
+    length, by 64 chains of hops side by side where the records are long enough to be told by their first
+    bytes, one after the other where not.  The chunks join up all the same, whichever launch works on them."""
     import os
     rng = np.random.default_rng(25)
     gaps = lambda i: 2 * i + 1
@@ -270,9 +271,13 @@ def test_compacted_batches_of_records_of_every_size(codec):
     # (one size for a stretch, then every size: the strides hand over to the hops inside a chunk)
     mixed = build_batch(dict(base_offset=60000, last_offset_delta=gaps(5999)),
                         records(6000, rng, od=gaps, value=lambda i: 100 if i % 1500 < 900 else 60 + int(v_len[i]) % 90))
-    small = [build_batch(dict(base_offset=90000 + 10 * i, last_offset_delta=9), records(10, rng)) for i in range(4)]
-    assert all(len(b) > 6 * CHUNK for b in (values, keys, mixed))
-    frame = patched(codec, small[:2] + [values, keys] + small[2:] + [mixed])
+    # (records of under 64 bytes, whose lengths take one byte: no chain of hops finds a start to begin at beside
+    # the first, and the records are counted one after the other)
+    short = build_batch(dict(base_offset=80000, last_offset_delta=gaps(15999)),
+                        records(16000, rng, od=gaps, value=lambda i: 18 + int(v_len[i % 12000]) % 20, key=lambda i: None))
+    small = [build_batch(dict(base_offset=190000 + 10 * i, last_offset_delta=9), records(10, rng)) for i in range(4)]
+    assert all(len(b) > 6 * CHUNK for b in (values, keys, mixed, short))
+    frame = patched(codec, small[:2] + [values, keys] + small[2:] + [mixed, short])
     for beside in ("1", "0"):
         os.environ["NISSHI_CHUNKS_BESIDE"] = beside
         os.environ["NISSHI_ADAPTIVE"] = "0"
