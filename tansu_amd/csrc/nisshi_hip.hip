@@ -2216,7 +2216,8 @@ __device__ __forceinline__ bool find_record_start(const View &ring, uint32_t bia
 // chunk's start is, and segments_join checks both -- a chunk's walk ends at the
 // record index that the next one started with only if every count before was right.
 // A chunk whose sizes change more often than kIndexTries times, or twice in a row
-// after a record or two, has its records counted one by one (hops_from).  The wave
+// after a record or two, has its records counted from length to length: by chains of
+// hops side by side (chains_from), or one by one (hops_from).  The wave
 // leaves its count for the waves of the chunks behind it and adds up those of the
 // chunks before it (decode_unit).
 constexpr int kIndexTries = 16;
