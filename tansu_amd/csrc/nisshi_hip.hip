@@ -2330,15 +2330,15 @@ __device__ __forceinline__ uint32_t hops_from(const uint8_t *grid, uint32_t limi
 // The same count by 64 chains of hops side by side, as chains_abreast finds the starts of a round:
 // the stretch is cut into 64 shares, lane 0's chain starts at pos and every other lane's at a
 // candidate, the first place in the first 192 bytes of its share that looks like the head of a
-// record (a length of two bytes that is not negative, an attributes byte of zero).  All chains hop in
+// record (a length of one or two bytes that is not negative, an attributes byte of zero, a byte that
+// is not zero two behind it: a delta).  All chains hop in
 // step, each through a view of the batch in memory of its own, until a chain lands exactly on the
 // start of a chain ahead of it (one it passes without landing on was no record's start: it aims at
 // the next).  The count is the sum over the chains on the path from lane 0's, which ends with the
 // chain that passes pos_end: nothing of a chain is used unless hops from pos led to where it
 // started.  kSegFailed (and the count is hops_from's): shares of less than 200 bytes, a chain on the
-// path that is still under way after kChainSteps hops (records of less than 64 bytes have lengths of
-// one byte and are no candidates), a hop that does not read as a record.
-constexpr uint32_t kChainSteps = 48, kChainScan = 16, kChainWindows = 3;  // hops a chain; dwords a window, windows a lane looks through for its candidate
+// path that is still under way after kChainSteps hops, a hop that does not read as a record.
+constexpr uint32_t kChainSteps = 64, kChainScan = 16, kChainWindows = 3;  // hops a chain; dwords a window, windows a lane looks through for its candidate
 __device__ __forceinline__ uint32_t chains_from(const uint8_t *grid, uint32_t limit, uint32_t bias, uint32_t pos,
                                                 uint32_t pos_end, uint32_t data_len, int lane) {
     typedef uint32_t __attribute__((aligned(4))) u32_al4;
@@ -2360,9 +2360,15 @@ __device__ __forceinline__ uint32_t chains_from(const uint8_t *grid, uint32_t li
         for (int j = (int)kChainScan - 1; j >= 0; j--) {
             uint32_t w = d[j], nx = d[j + 1];
             uint32_t b1 = __builtin_amdgcn_alignbit(nx, w, 8), b2 = __builtin_amdgcn_alignbit(nx, w, 16);
-            uint32_t nz = ((b2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | b2;  // bit 7 of a byte: the byte two on is not zero
-            // the byte continues, is even (no negative length), the next ends the varint, the one after is zero
-            uint32_t cand = w & ~(w << 7) & ~b1 & ~nz & 0x80808080u;
+            uint32_t b3 = __builtin_amdgcn_alignbit(nx, w, 24);
+            auto not_zero = [](uint32_t v) { return ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v; };  // bit 7 of every byte that is not zero
+            // the byte continues, is even (no negative length), the next ends the varint, the one after (the
+            // attributes) is zero -- and the byte two behind that is not: the end of a record without headers,
+            // "xx xx 00" and the next record's length and attributes, reads the same up to there
+            uint32_t cand = w & ~(w << 7) & ~b1 & ~not_zero(b2) & not_zero(nx) & 0x80808080u;
+            // or a length of one byte: the byte does not continue, is even and twelve at least (six bytes and
+            // more), the next is zero, the byte two behind that is not
+            cand |= ~w & ~(w << 7) & ((w & 0x7f7f7f7fu) + 0x74747474u) & ~not_zero(b1) & not_zero(b3) & 0x80808080u;
             uint32_t at = (uint32_t)j * 4 + ((uint32_t)__builtin_ctz(cand | 0x80000000u) >> 3);
             first = cand ? at : first;
         }

@@ -34,7 +34,9 @@ put("operators", {"note": "HIP-event kernel times (ms) at the C2 size: tools/sto
 put("inflate", {c: last_json(f"inflate_{c}") for c in ("snappy", "lz4", "gzip", "zstd")})
 put("deflate", {"lz4": last_json("deflate"), "gzip": last_json("deflate_gzip"), "zstd": last_json("deflate_zstd")})
 put("gapped_sizes", {"note": "tools/gapped_sizes_time.py: batches of 5000 records, every third gone, sizes drawn a record; "
-                             "`numbered`: the same batches with their records numbered 0, 1, 2 ...",
+                             "`numbered`: the same batches with their records numbered 0, 1, 2 ...; `short`: records of 21 to 53 bytes, no headers",
                      "batches_32": last_json("gapped_sizes_32"), "batches_32_numbered": last_json("gapped_sizes_32_numbered"),
-                     "batches_512": last_json("gapped_sizes_512"), "batches_512_numbered": last_json("gapped_sizes_512_numbered")})
+                     "batches_512": last_json("gapped_sizes_512"), "batches_512_numbered": last_json("gapped_sizes_512_numbered"),
+                     "batches_512_short": last_json("gapped_sizes_512_short"),
+                     "batches_512_short_numbered": last_json("gapped_sizes_512_short_numbered")})
 print("collected", tag, source_hash())

@@ -25,4 +25,6 @@ timeout -k 10 200 python3 tools/gapped_sizes_time.py --batches 32 > $o/${tag}_ga
 timeout -k 10 200 python3 tools/gapped_sizes_time.py --batches 32 --numbered > $o/${tag}_gapped_sizes_32_numbered.json 2>> $o/${tag}_gapped_sizes.err
 timeout -k 10 200 python3 tools/gapped_sizes_time.py > $o/${tag}_gapped_sizes_512.json 2>> $o/${tag}_gapped_sizes.err
 timeout -k 10 200 python3 tools/gapped_sizes_time.py --numbered > $o/${tag}_gapped_sizes_512_numbered.json 2>> $o/${tag}_gapped_sizes.err
+timeout -k 10 200 python3 tools/gapped_sizes_time.py --short > $o/${tag}_gapped_sizes_512_short.json 2>> $o/${tag}_gapped_sizes.err
+timeout -k 10 200 python3 tools/gapped_sizes_time.py --short --numbered > $o/${tag}_gapped_sizes_512_short_numbered.json 2>> $o/${tag}_gapped_sizes.err
 echo "compacted batches of changing sizes done"

@@ -1,5 +1,5 @@
 """Decode time of large compacted batches whose records change size from one to the next.
-python tools/gapped_sizes_time.py [<lib.so>] [--batches N] [--records R]
+python tools/gapped_sizes_time.py [<lib.so>] [--batches N] [--records R] [--numbered] [--short]
 N batches of R records (every third gone: offset deltas 0, 1, 3, 4, 6 ...; values of 32 to 96
 bytes and two headers of 0 to 32, drawn a record), checked against the CPU restatement on a
 sample, then timed over 20 enqueue-only decodes: one JSON line with the step, the kernels and
@@ -26,8 +26,10 @@ import torch  # noqa: E402
 
 n_batches, records = opt("--batches", 512), opt("--records", 5000)
 # (--numbered: the same batches with their records numbered 0, 1, 2 ..., for comparison)
+# (--short: records of 21 to 53 bytes, whose lengths take one byte: a key of 4 bytes, values of 8 to 40, no headers)
+short = dict(key_len=4, val_range=(8, 40), n_headers=0) if "--short" in sys.argv else {}
 blob, off, nr, nh = synth.make_var_batches(n_batches, records, synth.SEED_BASE + 9,
-                                           delta=None if "--numbered" in sys.argv else synth.every_third_missing)
+                                           delta=None if "--numbered" in sys.argv else synth.every_third_missing, **short)
 codec = hip.Codec(0)
 d_blob, d_off = codec.to_device(blob, off)
 cols = hip.DeviceColumns(n_batches, nr, max(nh, 1), codec.device)
