@@ -292,6 +292,23 @@ def test_compacted_batches_of_records_of_every_size(codec):
             fresh.close()
 
 
+@pytest.mark.parametrize("short", [False, True])
+def test_compacted_batches_of_every_size_by_the_hundred(codec, short):
+    """A hundred batches of 5000 records with every third gone and sizes drawn a record (values of 32 to 96
+    bytes and two headers; or, `short`, records of 21 to 53 bytes without headers, whose lengths take one
+    byte), every column held to the checker; the chunks of every batch join up."""
+    kind = dict(key_len=4, val_range=(8, 40), n_headers=0) if short else {}
+    blob, off, nr, nh = synth.make_var_batches(100, 5000, synth.SEED_BASE + 11, delta=synth.every_third_missing, **kind)
+    crc_patch(codec, blob, off)
+    fresh = hip.Codec(0)
+    try:
+        g, c, totals, *_ = check_against_oracle(fresh, blob, off)
+        assert (totals.n_records, totals.n_headers, totals.n_failed, totals.n_exact) == (nr, nh, 0, 0)
+        assert fresh.last_walked_whole() == 0
+    finally:
+        fresh.close()
+
+
 def test_compacted_batches_that_the_count_cannot_follow(codec):
     """The count looks at a few places a chunk and takes records of one size to lie between them, or goes
     from record to record up to a few thousand a chunk.  Where neither holds -- one record of another size
